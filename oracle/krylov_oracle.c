@@ -1,0 +1,590 @@
+/*
+ * krylov_oracle.c -- TEST INFRASTRUCTURE ONLY (see krylov_oracle.h).
+ *
+ * Line-faithful CPU restatement of the reference's serial BiCGStab(l) path.
+ * Every function names the reference lines it follows.  The pass structure is
+ * kept un-fused on purpose (separate scale / add passes, temporaries for b*s,
+ * two-pass norm, 27 loop nests per weighted dot): the same code is the
+ * single-core CPU baseline that is timed next to the GPU.
+ *
+ * Build: gcc -O3 -DNDEBUG -ffp-contract=off  (BICGStab3D/Makefile:6 uses -O3
+ * on x86 without FMA contraction).
+ *
+ * PARITY UNPINNED: no golden vectors exist in the reference; see the header.
+ */
+#include "krylov_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+/* ---- ghost-inclusive indexing ------------------------------------------ */
+
+typedef struct {
+	int mx, my, mz;     /* last point index */
+	long sx, sy;        /* row pitch, plane pitch */
+	long n;             /* stored doubles */
+} box_t;
+
+static box_t box_of(const orc_cfg *c)
+{
+	box_t b;
+	b.mx = c->mx[0]; b.my = c->mx[1]; b.mz = c->mx[2];
+	b.sx = b.mx + 3;
+	b.sy = b.sx * (long)(b.my + 3);
+	b.n = b.sy * (long)(b.mz + 3);
+	return b;
+}
+
+#define AT(b, a, i, j, k) ((a)[((long)(k) + 1) * (b).sy + ((long)(j) + 1) * (b).sx + ((i) + 1)])
+
+long orc_store_size(const orc_cfg *cfg) { return box_of(cfg).n; }
+
+static double sqr(double v) { return v * v; }
+
+static long long time_ms(void)
+{
+	struct timeval tv;
+	gettimeofday(&tv, NULL);
+	return (long long)tv.tv_sec * 1000LL + tv.tv_usec / 1000;
+}
+
+/* ---- whole-array operators of the external NumMatrix class --------------
+ * Call sites: solveLin_BICGStab.C:314,358,360,393,403,424,450-452,459-461 and
+ * Krylov.C:259,325.  They act on the full stored extent, ghosts included, and
+ * `x -= y*s` materialises the product in a temporary first. */
+
+static void arr_scale(long n, double *a, double s)
+{
+	for (long i = 0; i < n; ++i) a[i] *= s;
+}
+
+static void arr_add(long n, double *a, const double *b)
+{
+	for (long i = 0; i < n; ++i) a[i] += b[i];
+}
+
+static double *arr_times(long n, const double *b, double s)
+{
+	double *t = (double *)malloc((size_t)n * sizeof(double));
+	for (long i = 0; i < n; ++i) t[i] = b[i] * s;
+	return t;
+}
+
+static void arr_sub_scaled(long n, double *a, const double *b, double s)
+{
+	double *t = arr_times(n, b, s);
+	for (long i = 0; i < n; ++i) a[i] -= t[i];
+	free(t);
+}
+
+static void arr_add_scaled(long n, double *a, const double *b, double s)
+{
+	double *t = arr_times(n, b, s);
+	for (long i = 0; i < n; ++i) a[i] += t[i];
+	free(t);
+}
+
+/* ---- BoundaryHandler3D::do_BCs, rim = 1, all directions, serial ----------
+ * BICGStab3D/BoundaryHandler.C:370-575.  Dirichlet zeroes the boundary plane
+ * and the ghost plane.  "Neumann" is a linear extrapolation with asymmetric
+ * extents: the low x / low y faces fill the ghost only, the three high faces
+ * and the low z face also overwrite the boundary plane. */
+void orc_do_bcs(const orc_cfg *c, double *d)
+{
+	const box_t b = box_of(c);
+	const int rim = 1;
+	const int mx = b.mx, my = b.my, mz = b.mz;
+
+	/* x faces: BoundaryHandler.C:416-462 */
+	if (c->bc[0] == 0) {
+		for (int iy = -rim; iy <= my + rim; ++iy)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = -rim; ip <= 0; ++ip) AT(b, d, ip, iy, iz) = 0.;
+	} else if (c->bc[0] == 1) {
+		for (int iy = -rim; iy <= my + rim; ++iy)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = -1; ip >= -rim; --ip)
+					AT(b, d, ip, iy, iz) = 2. * AT(b, d, ip + 1, iy, iz) - AT(b, d, ip + 2, iy, iz);
+	}
+	if (c->bc[1] == 0) {
+		for (int iy = -rim; iy <= my + rim; ++iy)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = mx; ip <= mx + rim; ++ip) AT(b, d, ip, iy, iz) = 0.;
+	} else if (c->bc[1] == 1) {
+		for (int iy = -rim; iy <= my + rim; ++iy)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = mx; ip <= mx + rim; ++ip)
+					AT(b, d, ip, iy, iz) = 2. * AT(b, d, ip - 1, iy, iz) - AT(b, d, ip - 2, iy, iz);
+	}
+
+	/* y faces: BoundaryHandler.C:474-519 (x restricted to 0..mx) */
+	if (c->bc[2] == 0) {
+		for (int ix = 0; ix <= mx; ++ix)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = -rim; ip <= 0; ++ip) AT(b, d, ix, ip, iz) = 0.;
+	} else if (c->bc[2] == 1) {
+		for (int ix = 0; ix <= mx; ++ix)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = -1; ip >= -rim; --ip)
+					AT(b, d, ix, ip, iz) = 2. * AT(b, d, ix, ip + 1, iz) - AT(b, d, ix, ip + 2, iz);
+	}
+	if (c->bc[3] == 0) {
+		for (int ix = 0; ix <= mx; ++ix)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = my; ip <= my + rim; ++ip) AT(b, d, ix, ip, iz) = 0.;
+	} else if (c->bc[3] == 1) {
+		for (int ix = 0; ix <= mx; ++ix)
+			for (int iz = -rim; iz <= mz + rim; ++iz)
+				for (int ip = my; ip <= my + rim; ++ip)
+					AT(b, d, ix, ip, iz) = 2. * AT(b, d, ix, ip - 1, iz) - AT(b, d, ix, ip - 2, iz);
+	}
+
+	/* z faces: BoundaryHandler.C:525-568 (x, y restricted to 0..m; the low
+	 * face runs ip = -1 then 0, so the ghost uses the OLD plane 0) */
+	if (c->bc[4] == 0) {
+		for (int iy = 0; iy <= my; ++iy)
+			for (int ix = 0; ix <= mx; ++ix)
+				for (int ip = -rim; ip <= 0; ++ip) AT(b, d, ix, iy, ip) = 0.;
+	} else if (c->bc[4] == 1) {
+		for (int iy = 0; iy <= my; ++iy)
+			for (int ix = 0; ix <= mx; ++ix)
+				for (int ip = -rim; ip <= 0; ++ip)
+					AT(b, d, ix, iy, ip) = 2. * AT(b, d, ix, iy, ip + 1) - AT(b, d, ix, iy, ip + 2);
+	}
+	if (c->bc[5] == 0) {
+		for (int iy = 0; iy <= my; ++iy)
+			for (int ix = 0; ix <= mx; ++ix)
+				for (int ip = mz; ip <= mz + rim; ++ip) AT(b, d, ix, iy, ip) = 0.;
+	} else if (c->bc[5] == 1) {
+		for (int iy = 0; iy <= my; ++iy)
+			for (int ix = 0; ix <= mx; ++ix)
+				for (int ip = mz; ip <= mz + rim; ++ip)
+					AT(b, d, ix, iy, ip) = 2. * AT(b, d, ix, iy, ip - 1) - AT(b, d, ix, iy, ip - 2);
+	}
+}
+
+/* ---- Krylov::get_l2Norm, BICGStab3D/Krylov.C:36-157 -----------------------
+ * Max-scaled weighted sum of squares.  Faces 1/2, edges 1/4 and -- unlike the
+ * dot product -- the eight corners 1/4 as well (Krylov.C:136-143). */
+double orc_l2norm(const orc_cfg *c, const double *v)
+{
+	const box_t b = box_of(c);
+	const int mx = b.mx, my = b.my, mz = b.mz;
+
+	/* vec.max_norm() (Krylov.C:47): result discarded by line 57, the pass
+	 * itself is kept so the baseline does the same memory sweeps. */
+	volatile double sink = 0.;
+	{
+		double m = 0.;
+		for (long i = 0; i < b.n; ++i) { double a = fabs(v[i]); if (a > m) m = a; }
+		sink = m;
+	}
+	(void)sink;
+
+	double mymax = -10;
+	for (int iz = 0; iz <= mz; iz++)
+		for (int iy = 0; iy <= my; iy++)
+			for (int ix = 0; ix <= mx; ix++) {
+				double a = fabs(AT(b, v, ix, iy, iz));
+				mymax = (mymax < a) ? a : mymax;   /* std::max(mymax, a) */
+			}
+	double valMax = mymax;
+
+	if (valMax == 0.) return 0;
+	double scaleFactor = 1. / valMax;
+
+	double sum = 0.;
+	for (int iz = 1; iz < mz; iz++)
+		for (int iy = 1; iy < my; iy++)
+			for (int ix = 1; ix < mx; ix++) {
+				double valScale = scaleFactor * AT(b, v, ix, iy, iz);
+				sum += sqr(valScale);
+			}
+
+	for (int iz = 1; iz < mz; iz++)
+		for (int iy = 1; iy < my; iy++) {
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, 0, iy, iz));
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, mx, iy, iz));
+		}
+	for (int iz = 1; iz < mz; iz++)
+		for (int ix = 1; ix < mx; ix++) {
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, ix, 0, iz));
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, ix, my, iz));
+		}
+	for (int iy = 1; iy < my; iy++)
+		for (int ix = 1; ix < mx; ix++) {
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, ix, iy, 0));
+			sum += 0.5 * sqr(scaleFactor * AT(b, v, ix, iy, mz));
+		}
+
+	for (int iz = 1; iz < mz; ++iz) {
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, 0, iz));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, my, iz));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, 0, iz));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, my, iz));
+	}
+	for (int iy = 1; iy < my; ++iy) {
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, iy, 0));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, iy, mz));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, iy, 0));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, iy, mz));
+	}
+	for (int ix = 1; ix < mx; ++ix) {
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, ix, 0, 0));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, ix, 0, mz));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, ix, my, 0));
+		sum += 0.25 * sqr(scaleFactor * AT(b, v, ix, my, mz));
+	}
+
+	/* corners: weight 1/4 in the reference's norm (its comment says 1/8) */
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, 0, 0));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, my, 0));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, 0, mz));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, 0, my, mz));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, 0, 0));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, my, 0));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, 0, mz));
+	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, my, mz));
+
+	return valMax * sqrt(sum);
+}
+
+/* ---- Krylov::dot_product, BICGStab3D/Krylov.C:161-244 --------------------- */
+double orc_dot(const orc_cfg *c, const double *A, const double *B)
+{
+	const box_t b = box_of(c);
+	const int mx = b.mx, my = b.my, mz = b.mz;
+	double result = 0.;
+
+	for (int iz = 1; iz < mz; iz++)
+		for (int iy = 1; iy < my; iy++)
+			for (int ix = 1; ix < mx; ix++)
+				result += AT(b, A, ix, iy, iz) * AT(b, B, ix, iy, iz);
+
+	for (int iz = 1; iz < mz; iz++)
+		for (int iy = 1; iy < my; iy++) {
+			result += 0.5 * AT(b, A, 0, iy, iz) * AT(b, B, 0, iy, iz);
+			result += 0.5 * AT(b, A, mx, iy, iz) * AT(b, B, mx, iy, iz);
+		}
+	for (int iz = 1; iz < mz; iz++)
+		for (int ix = 1; ix < mx; ix++) {
+			result += 0.5 * AT(b, A, ix, 0, iz) * AT(b, B, ix, 0, iz);
+			result += 0.5 * AT(b, A, ix, my, iz) * AT(b, B, ix, my, iz);
+		}
+	for (int iy = 1; iy < my; iy++)
+		for (int ix = 1; ix < mx; ix++) {
+			result += 0.5 * AT(b, A, ix, iy, 0) * AT(b, B, ix, iy, 0);
+			result += 0.5 * AT(b, A, ix, iy, mz) * AT(b, B, ix, iy, mz);
+		}
+
+	for (int iz = 1; iz < mz; iz++) {
+		result += 0.25 * AT(b, A, 0, 0, iz) * AT(b, B, 0, 0, iz);
+		result += 0.25 * AT(b, A, mx, 0, iz) * AT(b, B, mx, 0, iz);
+		result += 0.25 * AT(b, A, 0, my, iz) * AT(b, B, 0, my, iz);
+		result += 0.25 * AT(b, A, mx, my, iz) * AT(b, B, mx, my, iz);
+	}
+	for (int iy = 1; iy < my; iy++) {
+		result += 0.25 * AT(b, A, 0, iy, 0) * AT(b, B, 0, iy, 0);
+		result += 0.25 * AT(b, A, mx, iy, 0) * AT(b, B, mx, iy, 0);
+		result += 0.25 * AT(b, A, 0, iy, mz) * AT(b, B, 0, iy, mz);
+		result += 0.25 * AT(b, A, mx, iy, mz) * AT(b, B, mx, iy, mz);
+	}
+	for (int ix = 1; ix < mx; ix++) {
+		result += 0.25 * AT(b, A, ix, 0, 0) * AT(b, B, ix, 0, 0);
+		result += 0.25 * AT(b, A, ix, my, 0) * AT(b, B, ix, my, 0);
+		result += 0.25 * AT(b, A, ix, 0, mz) * AT(b, B, ix, 0, mz);
+		result += 0.25 * AT(b, A, ix, my, mz) * AT(b, B, ix, my, mz);
+	}
+
+	result += 0.125 * AT(b, A, 0, 0, 0) * AT(b, B, 0, 0, 0);
+	result += 0.125 * AT(b, A, mx, 0, 0) * AT(b, B, mx, 0, 0);
+	result += 0.125 * AT(b, A, 0, my, 0) * AT(b, B, 0, my, 0);
+	result += 0.125 * AT(b, A, mx, my, 0) * AT(b, B, mx, my, 0);
+	result += 0.125 * AT(b, A, 0, 0, mz) * AT(b, B, 0, 0, mz);
+	result += 0.125 * AT(b, A, mx, 0, mz) * AT(b, B, mx, 0, mz);
+	result += 0.125 * AT(b, A, 0, my, mz) * AT(b, B, 0, my, mz);
+	result += 0.125 * AT(b, A, mx, my, mz) * AT(b, B, mx, my, mz);
+	return result;
+}
+
+/* ---- Krylov::multiply_withMat, constant coefficients ----------------------
+ * BICGStab3D/Krylov.C:500-541.  Applies do_BCs to its INPUT first (line 516),
+ * evaluates the 7-point expression on every point 0..mx, then do_BCs on the
+ * output when apply_bcs is set. */
+void orc_spmv_const(const orc_cfg *c, double *psi, const double *lambda,
+                    double *out, int apply_bcs)
+{
+	const box_t b = box_of(c);
+	double coeff[3];
+	for (int d = 0; d < 3; ++d) coeff[d] = c->Dc[d] / sqr(c->delx[d]);
+
+	orc_do_bcs(c, psi);
+
+	for (int iz = 0; iz <= b.mz; iz++)
+		for (int iy = 0; iy <= b.my; iy++)
+			for (int ix = 0; ix <= b.mx; ix++) {
+				const double value =
+				    (coeff[0] * (AT(b, psi, ix + 1, iy, iz) + AT(b, psi, ix - 1, iy, iz)) +
+				     coeff[1] * (AT(b, psi, ix, iy + 1, iz) + AT(b, psi, ix, iy - 1, iz)) +
+				     coeff[2] * (AT(b, psi, ix, iy, iz + 1) + AT(b, psi, ix, iy, iz - 1)) -
+				     (2. * (coeff[0] + coeff[1] + coeff[2]) + AT(b, lambda, ix, iy, iz)) *
+				         AT(b, psi, ix, iy, iz));
+				AT(b, out, ix, iy, iz) = value;
+			}
+
+	if (apply_bcs) orc_do_bcs(c, out);
+}
+
+/* ---- Krylov::multiply_withMat, coefficient fields -------------------------
+ * BICGStab3D/Krylov.C:407-496.  No boundary treatment of the input. */
+void orc_spmv_var(const orc_cfg *c, const double *psi, const double *lambda,
+                  const double *Dxx, const double *Dyy, const double *Dzz,
+                  const double *Dxy, double *out, int apply_bcs)
+{
+	const box_t b = box_of(c);
+	const double *delx = c->delx;
+	double coeff[3];
+	for (int d = 0; d < 3; ++d) coeff[d] = 1. / sqr(delx[d]);
+	const double coeff_xy = 1. / (2. * delx[0] * delx[1]);
+
+	for (int iz = 0; iz <= b.mz; iz++)
+		for (int iy = 0; iy <= b.my; iy++)
+			for (int ix = 0; ix <= b.mx; ix++) {
+				AT(b, out, ix, iy, iz) =
+				    (coeff[0] * AT(b, Dxx, ix, iy, iz) *
+				         (AT(b, psi, ix + 1, iy, iz) + AT(b, psi, ix - 1, iy, iz)) +
+				     coeff[1] * AT(b, Dyy, ix, iy, iz) *
+				         (AT(b, psi, ix, iy + 1, iz) + AT(b, psi, ix, iy - 1, iz)) +
+				     coeff[2] * AT(b, Dzz, ix, iy, iz) *
+				         (AT(b, psi, ix, iy, iz + 1) + AT(b, psi, ix, iy, iz - 1)) -
+				     (2. * (coeff[0] * AT(b, Dxx, ix, iy, iz) + coeff[1] * AT(b, Dyy, ix, iy, iz) +
+				            coeff[2] * AT(b, Dzz, ix, iy, iz)) +
+				      AT(b, lambda, ix, iy, iz)) *
+				         AT(b, psi, ix, iy, iz) +
+
+				     coeff_xy * AT(b, Dxy, ix, iy, iz) *
+				         (AT(b, psi, ix + 1, iy + 1, iz) - AT(b, psi, ix + 1, iy - 1, iz) -
+				          AT(b, psi, ix - 1, iy + 1, iz) + AT(b, psi, ix - 1, iy - 1, iz)) +
+				     ((AT(b, Dxx, ix + 1, iy, iz) - AT(b, Dxx, ix - 1, iy, iz)) / (2. * delx[0]) +
+				      (AT(b, Dxy, ix, iy + 1, iz) - AT(b, Dxy, ix, iy - 1, iz)) / (2. * delx[1])) *
+				         (AT(b, psi, ix + 1, iy, iz) - AT(b, psi, ix - 1, iy, iz)) / (2. * delx[0]) +
+				     ((AT(b, Dxy, ix + 1, iy, iz) - AT(b, Dxy, ix - 1, iy, iz)) / (2. * delx[0]) +
+				      (AT(b, Dyy, ix, iy + 1, iz) - AT(b, Dyy, ix, iy - 1, iz)) / (2. * delx[1])) *
+				         (AT(b, psi, ix, iy + 1, iz) - AT(b, psi, ix, iy - 1, iz)) / (2. * delx[1]) +
+				     ((AT(b, Dzz, ix, iy, iz + 1) - AT(b, Dzz, ix, iy, iz - 1)) / (2. * delx[2])) *
+				         (AT(b, psi, ix, iy, iz + 1) - AT(b, psi, ix, iy, iz - 1)) / (2. * delx[2]));
+			}
+
+	if (apply_bcs) orc_do_bcs(c, out);
+}
+
+/* ---- Krylov::reallyIsNan(float), BICGStab3D/Krylov.C:553-559 --------------
+ * The double is narrowed to float first: NaN, Inf and any magnitude beyond
+ * FLT_MAX all report true. */
+int orc_really_is_nan(double xd)
+{
+	float x = (float)xd;
+	int bits;
+	memcpy(&bits, &x, sizeof bits);
+	return (bits & 0x7F800000) == 0x7F800000;
+}
+
+/* ---- Krylov::get_Residual, BICGStab3D/Krylov.C:248-306 and 311-402 -------- */
+static void residual(const orc_cfg *c, double *phi, const double *rhs, const double *lambda,
+                     const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy,
+                     double *res)
+{
+	const box_t b = box_of(c);
+	if (c->var_coef) orc_spmv_var(c, phi, lambda, Dxx, Dyy, Dzz, Dxy, res, 0);
+	else             orc_spmv_const(c, phi, lambda, res, 0);
+	/* residual = rhs - residual: temporary, then assignment */
+	double *t = (double *)malloc((size_t)b.n * sizeof(double));
+	for (long i = 0; i < b.n; ++i) t[i] = rhs[i] - res[i];
+	memcpy(res, t, (size_t)b.n * sizeof(double));
+	free(t);
+	orc_do_bcs(c, res);
+}
+
+static void spmv(const orc_cfg *c, double *psi, const double *lambda,
+                 const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy,
+                 double *out)
+{
+	if (c->var_coef) orc_spmv_var(c, psi, lambda, Dxx, Dyy, Dzz, Dxy, out, 1);
+	else             orc_spmv_const(c, psi, lambda, out, 1);
+}
+
+/* ---- BICGStab::solve + solve_int, BICGStab3D/solveLin_BICGStab.C:200-527 --- */
+int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
+              double *Dxx, double *Dyy, double *Dzz, double *Dxy,
+              double *hist, int hist_cap, orc_out *out)
+{
+	const box_t b = box_of(c);
+	const long n = b.n;
+	const int L = c->L;
+	const double eps = c->eps;
+	orc_out o;
+	memset(&o, 0, sizeof o);
+
+	/* solve(): the field overload clears Dxy unless off-diagonal diffusion is
+	 * requested (solveLin_BICGStab.C:231-233); the constant overload passes rhs
+	 * in place of all four coefficient fields (line 214). */
+	if (c->var_coef) {
+		if (!c->use_offdiag) memset(Dxy, 0, (size_t)n * sizeof(double));
+	} else {
+		Dxx = Dyy = Dzz = Dxy = rhs;
+	}
+
+	double normRHS = orc_l2norm(c, rhs);                     /* :268 */
+	if (normRHS == 0.) normRHS = 1.;                         /* :269 */
+	o.norm_rhs = normRHS;
+
+	/* make_Arrays (:175-191): zero-filled work vectors */
+	double **r = (double **)malloc((size_t)(L + 1) * sizeof(double *));
+	double **u = (double **)malloc((size_t)(L + 1) * sizeof(double *));
+	for (int k = 0; k <= L; ++k) {
+		r[k] = (double *)calloc((size_t)n, sizeof(double));
+		u[k] = (double *)calloc((size_t)n, sizeof(double));
+	}
+	double *rt = (double *)calloc((size_t)n, sizeof(double));
+
+	int iter_steps = 0;
+	residual(c, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy, r[0]); /* :294-299 */
+	double norm_init = orc_l2norm(c, r[0]);                  /* :301 */
+	o.norm_init = norm_init;
+
+	double norm = 1.e99;
+	if (norm_init < eps * normRHS) {                         /* :303-311 */
+		if (c->debug > 2) {
+			printf(" Initial Norm: %g %g %g %g %d\n", norm_init, norm_init / normRHS,
+			       normRHS, eps * normRHS, iter_steps);
+			printf(" Doing no iterations \n");
+		}
+		o.norm_final = norm_init;
+		o.norm_true = norm_init;
+		goto done;
+	}
+
+	memcpy(rt, r[0], (size_t)n * sizeof(double));            /* :314 */
+
+	{
+		double rho0 = 1., rho1;
+		double alpha = 0.;
+		double omega = 1.;
+		/* VLAs as in :322-324 */
+		double tau[L + 1][L + 1];
+		double sigma[L + 1], gammap[L + 1], gammapp[L + 1], gamma[L + 1];
+
+		long long iteration_runtime = -time_ms();
+		do {
+			iter_steps++;
+			if (c->debug > 2) {                              /* :330-339 */
+				printf(" Iteration: %d", iter_steps);
+				if (iter_steps > 1) {
+					iteration_runtime += time_ms();
+					printf(" (%lld ms)", iteration_runtime);
+				}
+				printf("\n");
+				iteration_runtime = -time_ms();
+			}
+
+			rho0 *= -omega;                                  /* :341 */
+
+			/* BiCG part, :345-410 */
+			for (int jj = 0; jj < L; ++jj) {
+				rho1 = orc_dot(c, r[jj], rt);                /* :349 */
+				double beta = alpha * rho1 / rho0;           /* :351 */
+				rho0 = rho1;
+
+				for (int ii = 0; ii <= jj; ++ii) {           /* :356-362 */
+					arr_scale(n, u[ii], -beta);
+					arr_add(n, u[ii], r[ii]);
+				}
+
+				spmv(c, u[jj], lambda, Dxx, Dyy, Dzz, Dxy, u[jj + 1]);   /* :374-378 */
+
+				alpha = rho0 / orc_dot(c, u[jj + 1], rt);    /* :390 */
+
+				for (int ii = 0; ii <= jj; ++ii)             /* :392-394 */
+					arr_sub_scaled(n, r[ii], u[ii + 1], alpha);
+
+				spmv(c, r[jj], lambda, Dxx, Dyy, Dzz, Dxy, r[jj + 1]);   /* :397-401 */
+
+				arr_add_scaled(n, phi, u[0], alpha);         /* :403 */
+
+				if (orc_really_is_nan(alpha)) {              /* :406-409 */
+					printf(" alpha is nan %d %g %g %g\n", jj, rho0, rho1, beta);
+					o.status = 1;
+					goto stop;
+				}
+			}
+
+			/* MR part, :419-430 */
+			for (int jj = 1; jj <= L; ++jj) {
+				for (int ii = 1; ii < jj; ++ii) {
+					tau[ii][jj] = orc_dot(c, r[jj], r[ii]) / sigma[ii];
+					arr_sub_scaled(n, r[jj], r[ii], tau[ii][jj]);
+				}
+				sigma[jj] = orc_dot(c, r[jj], r[jj]);
+				gammap[jj] = orc_dot(c, r[0], r[jj]) / sigma[jj];
+			}
+			omega = gamma[L] = gammap[L];                    /* :431 */
+
+			for (int jj = L - 1; jj >= 1; --jj) {            /* :434-439 */
+				gamma[jj] = gammap[jj];
+				for (int ii = jj + 1; ii <= L; ++ii) gamma[jj] -= tau[jj][ii] * gamma[ii];
+			}
+			for (int jj = 1; jj < L; ++jj) {                 /* :441-446 */
+				gammapp[jj] = gamma[jj + 1];
+				for (int ii = jj + 1; ii < L; ++ii) gammapp[jj] += tau[jj][ii] * gamma[ii + 1];
+			}
+
+			arr_add_scaled(n, phi, r[0], gamma[1]);          /* :450 */
+			arr_sub_scaled(n, r[0], r[L], gammap[L]);        /* :451 */
+			arr_sub_scaled(n, u[0], u[L], gamma[L]);         /* :452 */
+
+			for (int jj = 1; jj < L; ++jj) {                 /* :458-462 */
+				arr_sub_scaled(n, u[0], u[jj], gamma[jj]);
+				arr_add_scaled(n, phi, r[jj], gammapp[jj]);
+				arr_sub_scaled(n, r[0], r[jj], gammap[jj]);
+			}
+
+			norm = orc_l2norm(c, r[0]);                      /* :464 */
+			if (hist && iter_steps <= hist_cap) hist[iter_steps - 1] = norm;
+			if (c->debug > 2)                                /* :465-469 */
+				printf(" My error norm: %g %g %g %g %g \n", norm, sqrt(norm), eps * normRHS, eps,
+				       normRHS);
+
+			if (orc_really_is_nan(norm)) {                   /* :491-494 */
+				printf(" Norm is nan at iteration %d\n", iter_steps);
+				o.status = 3;
+				goto stop;
+			}
+			if (c->max_outer > 0 && iter_steps >= c->max_outer && norm > eps * normRHS) {
+				o.status = 4;       /* cap is an addition; the reference has none */
+				break;
+			}
+		} while (norm > eps * normRHS);                      /* :496 */
+
+		if (c->debug > 2) {                                  /* :498-507 */
+			printf(" Final error: %g after %d iterations \n", norm, iter_steps);
+			printf(" Norm: %g %g %g %g %d\n", norm, norm / normRHS, normRHS, eps * normRHS,
+			       iter_steps);
+		}
+	}
+
+	/* true residual once more (:512-518); the reference discards the value */
+	residual(c, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy, r[0]);
+	o.norm_true = orc_l2norm(c, r[0]);
+
+stop:
+	o.norm_final = norm;
+done:
+	o.iters = iter_steps;
+	for (int k = 0; k <= L; ++k) { free(r[k]); free(u[k]); }
+	free(r); free(u); free(rt);
+	if (out) *out = o;
+	return o.status;
+}

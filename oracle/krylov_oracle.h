@@ -1,0 +1,77 @@
+/*
+ * krylov_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99, single thread) of the reference's BiCGStab(l)
+ * stencil solve:  BICGStab3D/solveLin_BICGStab.C, BICGStab3D/Krylov.C and
+ * BoundaryHandler3D::do_BCs of BICGStab3D/BoundaryHandler.C (serial build,
+ * i.e. compiled without -D parallel).
+ *
+ * It exists to CHECK the HIP path.  Only tests/, __graft_entry__.smoke() and
+ * the cpu_baseline leg of bench.py may load it.  Nothing in krylov_amd/ links,
+ * imports or calls it.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors for this path and
+ * its sources cannot be built here (the array library matrix.H they depend on
+ * is not part of the reference tree).  The restatement follows the cited
+ * lines operation by operation and is compiled with -ffp-contract=off so that
+ * no fused multiply-add changes a rounding; it is sanity-anchored by the
+ * analytic solutions of the reference driver (BICGStab3D/main.C:276-396).
+ *
+ * Array layout: every field is a ghost-inclusive box [-1..mx+1]^3, x fastest:
+ *   index(i,j,k) = ((k+1)*(my+3) + (j+1))*(mx+3) + (i+1).
+ */
+#ifndef KRYLOV_ORACLE_H
+#define KRYLOV_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int mx[3];        /* last grid-point index per direction (points 0..mx) */
+	double delx[3];   /* grid spacing */
+	int bc[6];        /* xlo,xhi,ylo,yhi,zlo,zhi: 0 Dirichlet, 1 "Neumann"
+	                     (linear extrapolation), anything else: untouched */
+	int L;            /* BiCGStab(l) polynomial degree */
+	double eps;       /* relative tolerance */
+	int max_outer;    /* 0 = unlimited (reference behaviour) */
+	int var_coef;     /* 0: constant-coefficient overload; 1: field overload */
+	int use_offdiag;  /* field overload: 0 clears Dxy first (as the reference) */
+	double Dc[3];     /* constant D_xx, D_yy, D_zz */
+	int debug;        /* >2 prints the reference's per-iteration lines */
+} orc_cfg;
+
+typedef struct {
+	int iters;            /* outer iterations executed */
+	int status;           /* 0 ok, 1 alpha nan (ref exit(1)), 3 norm nan (ref exit(3)),
+	                         4 stopped by max_outer */
+	double norm_rhs;      /* normRHS after the zero -> one substitution */
+	double norm_init;     /* l2 of the first residual */
+	double norm_final;    /* last value of `norm` in the loop */
+	double norm_true;     /* l2 of rhs - A phi recomputed after the loop */
+} orc_out;
+
+/* Whole solve.  phi is in/out; rhs/lambda/D* are inputs but may be modified
+ * exactly where the reference modifies them (Dxy cleared, do_BCs on phi via the
+ * constant-coefficient operator).  hist receives `norm` of each outer
+ * iteration (up to hist_cap entries).  Returns out->status. */
+int orc_solve(const orc_cfg *cfg, double *phi, double *rhs, double *lambda,
+              double *Dxx, double *Dyy, double *Dzz, double *Dxy,
+              double *hist, int hist_cap, orc_out *out);
+
+/* Building blocks, exported for kernel-level parity tests. */
+void   orc_do_bcs(const orc_cfg *cfg, double *a);
+void   orc_spmv_const(const orc_cfg *cfg, double *psi, const double *lambda,
+                      double *out, int apply_bcs);
+void   orc_spmv_var(const orc_cfg *cfg, const double *psi, const double *lambda,
+                    const double *Dxx, const double *Dyy, const double *Dzz,
+                    const double *Dxy, double *out, int apply_bcs);
+double orc_dot(const orc_cfg *cfg, const double *a, const double *b);
+double orc_l2norm(const orc_cfg *cfg, const double *v);
+int    orc_really_is_nan(double x);
+long   orc_store_size(const orc_cfg *cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""ctypes binding of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Loaded by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of
+bench.py.  Nothing under krylov_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libkrylov_oracle.so")
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [
+        ("mx", C.c_int * 3),
+        ("delx", C.c_double * 3),
+        ("bc", C.c_int * 6),
+        ("L", C.c_int),
+        ("eps", C.c_double),
+        ("max_outer", C.c_int),
+        ("var_coef", C.c_int),
+        ("use_offdiag", C.c_int),
+        ("Dc", C.c_double * 3),
+        ("debug", C.c_int),
+    ]
+
+
+class OrcOut(C.Structure):
+    _fields_ = [
+        ("iters", C.c_int),
+        ("status", C.c_int),
+        ("norm_rhs", C.c_double),
+        ("norm_init", C.c_double),
+        ("norm_final", C.c_double),
+        ("norm_true", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "krylov_oracle.c")
+    if (not force and os.path.exists(_LIB)
+            and os.path.getmtime(_LIB) >= os.path.getmtime(src)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        P = C.POINTER
+        L.orc_solve.restype = C.c_int
+        L.orc_solve.argtypes = [P(OrcCfg), _dp, _dp, _dp, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, _dp, C.c_int, P(OrcOut)]
+        L.orc_do_bcs.restype = None
+        L.orc_do_bcs.argtypes = [P(OrcCfg), _dp]
+        L.orc_spmv_const.restype = None
+        L.orc_spmv_const.argtypes = [P(OrcCfg), _dp, _dp, _dp, C.c_int]
+        L.orc_spmv_var.restype = None
+        L.orc_spmv_var.argtypes = [P(OrcCfg), _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int]
+        L.orc_dot.restype = C.c_double
+        L.orc_dot.argtypes = [P(OrcCfg), _dp, _dp]
+        L.orc_l2norm.restype = C.c_double
+        L.orc_l2norm.argtypes = [P(OrcCfg), _dp]
+        L.orc_really_is_nan.restype = C.c_int
+        L.orc_really_is_nan.argtypes = [C.c_double]
+        L.orc_store_size.restype = C.c_long
+        L.orc_store_size.argtypes = [P(OrcCfg)]
+        _lib = L
+    return _lib
+
+
+def make_cfg(mx, delx, bc=(0,) * 6, L=2, eps=1e-6, max_outer=0, var_coef=False,
+             use_offdiag=False, Dc=(1., 1., 1.), debug=0):
+    c = OrcCfg()
+    for d in range(3):
+        c.mx[d] = int(mx[d])
+        c.delx[d] = float(delx[d])
+        c.Dc[d] = float(Dc[d])
+    for f in range(6):
+        c.bc[f] = int(bc[f])
+    c.L = int(L)
+    c.eps = float(eps)
+    c.max_outer = int(max_outer)
+    c.var_coef = int(bool(var_coef))
+    c.use_offdiag = int(bool(use_offdiag))
+    c.debug = int(debug)
+    return c
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def solve(cfg, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4096):
+    """Run the oracle solve.  phi is updated in place.  Arrays are the
+    ghost-inclusive boxes, shape (mz+3, my+3, mx+3), C order (x fastest)."""
+    hist = np.zeros(max(hist_cap, 1), dtype=np.float64)
+    out = OrcOut()
+    st = lib().orc_solve(C.byref(cfg), phi, rhs, lam, _ptr(Dxx), _ptr(Dyy), _ptr(Dzz),
+                         _ptr(Dxy), hist, hist_cap, C.byref(out))
+    n = min(out.iters, hist_cap)
+    return dict(status=st, iters=out.iters, norm_rhs=out.norm_rhs, norm_init=out.norm_init,
+                norm_final=out.norm_final, norm_true=out.norm_true, history=hist[:n].copy())
+
+
+def do_bcs(cfg, a):
+    lib().orc_do_bcs(C.byref(cfg), a)
+
+
+def spmv_const(cfg, psi, lam, apply_bcs=True):
+    out = np.zeros_like(psi)
+    lib().orc_spmv_const(C.byref(cfg), psi, lam, out, int(apply_bcs))
+    return out
+
+
+def spmv_var(cfg, psi, lam, Dxx, Dyy, Dzz, Dxy, apply_bcs=True):
+    out = np.zeros_like(psi)
+    lib().orc_spmv_var(C.byref(cfg), psi, lam, Dxx, Dyy, Dzz, Dxy, out, int(apply_bcs))
+    return out
+
+
+def dot(cfg, a, b):
+    return lib().orc_dot(C.byref(cfg), a, b)
+
+
+def l2norm(cfg, v):
+    return lib().orc_l2norm(C.byref(cfg), v)
+
+
+def really_is_nan(x):
+    return bool(lib().orc_really_is_nan(float(x)))
