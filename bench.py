@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Throughput of the BiCGStab(l) stencil solve on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" is one pass of the outer do{}while loop of the reference's
+solve_int (BICGStab3D/solveLin_BICGStab.C:327-496): 2*l operator
+applications, the vector updates and all dot products.  The workload is the
+512^3 fp64 variable-coefficient stencil (Dxy = 0) with Dirichlet faces; with N
+GPUs the grid is split into N z-slabs (strong scaling: total work fixed).
+Fields are generated on the host, staged to HBM and the solve's prologue is
+run before the timed region; the timed region is K passes on resident data.
+
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (HIP events
+recorded on the solver's own stream around every launch of the timed region);
+`cpu_baseline` is the CPU oracle (oracle/, a line-faithful restatement of the
+reference's serial path) timed on one host core on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+KIND_NAMES = {0: "fused_A0", 1: "fused_A1", 2: "fused_B0", 3: "fused_B0L", 4: "fused_B1L",
+              5: "fused_residual", 6: "mgs2", 7: "final"}
+
+
+def kernel_words(L, var, offd):
+    """Doubles read + written per grid point by each kernel of one pass (every
+    array touched once per kernel, stencil neighbours served on chip)."""
+    d = (4 if offd else 3) if var else 0
+    if L == 1:
+        return {0: 6 + d,          # r0,u0,lam,rt -> u0,u1
+                3: 5 + d,          # r0,u1,lam -> r0,r1
+                7: 9}              # phi,u0,r0,r1,u1,rt -> phi,r0,u0
+    return {0: 6 + d,              # r0,u0,lam,rt -> u0,u1
+            2: 6 + d,              # r0,u1,lam,rt -> r0,r1
+            1: 11 + d,             # r1,u1,lam,rt,phi,u0,r0 -> u1,u2,phi,u0
+            4: 8 + d,              # r1,u2,lam,r0,u1 -> r1,r2,r0
+            6: 4,                  # r2,r1,r0 -> r2
+            7: 11}                 # phi,r0..r2,u0..u2,rt -> phi,r0,u0
+
+
+def slab_problem(n, nslabs, slab, workload):
+    """Fields of z-slab `slab` of the n^3 problem, ghost planes included,
+    evaluated from closed forms at global positions."""
+    from krylov_amd import problems as P
+    mzl = n // nslabs
+    delx = (1.0 / n,) * 3
+    ax = [np.arange(-1, n + 2, dtype=np.float64) * delx[0],
+          np.arange(-1, n + 2, dtype=np.float64) * delx[1],
+          (np.arange(-1, mzl + 2, dtype=np.float64) + slab * mzl) * delx[2]]
+    z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij", sparse=True)
+    pi = np.pi
+    shape = (mzl + 3, n + 3, n + 3)
+    full = lambda a: np.ascontiguousarray(np.broadcast_to(a, shape))
+    f = {}
+    f["lam"] = full(0.2 * x * (y * y) * z)
+    sinx, siny, sinz = np.sin(pi * x), np.sin(pi * y), np.sin(pi * z)
+    if workload == "var":
+        f["Dxx"] = full(1.0 + 0.5 * np.sin(2 * pi * x) * np.cos(2 * pi * y))
+        f["Dyy"] = full(1.0 + 0.5 * np.sin(2 * pi * y) * np.cos(2 * pi * z))
+        f["Dzz"] = full(1.0 + 0.5 * np.sin(2 * pi * z) * np.cos(2 * pi * x))
+        f["rhs"] = full(sinx * siny * sinz)
+        f["Dc"] = (1., 1., 1.)
+    else:
+        # the reference driver's test 1 (BICGStab3D/main.C:223-229,277,282-284)
+        Dc = (1., 1., 10.)
+        f["rhs"] = full(-((pi * pi) * (Dc[0] + Dc[1] + Dc[2]) + f["lam"]) * (sinx * siny * sinz))
+        f["Dc"] = Dc
+    f["phi"] = np.zeros(shape)
+    f["mx"] = (n, n, mzl)
+    f["delx"] = delx
+    return f
+
+
+def cpu_baseline(n_sample, L, workload, n_full, budget_iters):
+    """CPU oracle on one core, same workload at n_sample^3, a few passes."""
+    from oracle import oracle as orc
+    orc.build()
+    f = slab_problem(n_sample, 1, 0, workload)
+    var = workload == "var"
+    cfg = orc.make_cfg(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=budget_iters,
+                       var_coef=var, use_offdiag=False, Dc=f["Dc"])
+    phi = f["phi"].copy()
+    z = np.zeros_like(phi) if var else None
+    t0 = time.perf_counter()
+    r = orc.solve(cfg, phi, f["rhs"].copy(), f["lam"].copy(), f.get("Dxx"), f.get("Dyy"), f.get("Dzz"), z)
+    dt = time.perf_counter() - t0
+    its = max(r["iters"], 1)
+    rate_sample = its / dt
+    scale = ((n_sample + 1) ** 3) / float((n_full + 1) ** 3)
+    return {"value": rate_sample * scale, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": "%d passes (plus prologue/epilogue residuals) of the same %s-coefficient l=%d solve at "
+                      "%d^3 on one core: %.3f iter/s measured, scaled by grid points to %d^3"
+                      % (its, workload, L, n_sample, rate_sample, n_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=512, help="grid size (points 0..n per direction)")
+    ap.add_argument("--L", type=int, default=2, help="BiCGStab(l) degree; the reference drivers use 2")
+    ap.add_argument("--workload", choices=["var", "const"], default="var")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-n", type=int, default=192)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    os.environ.setdefault("KRY_PROFILE", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    # the solver library first (it binds the ROCm installation's HIP runtime),
+    # torch.distributed afterwards and for the control plane only
+    from krylov_amd import capi
+    capi.lib()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+
+    n, L, var = args.n, args.L, args.workload == "var"
+    if n % world != 0:
+        sys.exit("grid size %d is not divisible by %d slabs" % (n, world))
+    f = slab_problem(n, world, rank, args.workload)
+
+    solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
+                         slab_begin=rank, slab_count=1, devices=(local_rank,))
+    if world > 1:
+        import torch
+        uid = [capi.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        solver.comm_init(uid[0], rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    t_stage = time.perf_counter()
+    if var:
+        solver.load_var(f["phi"], f["rhs"], f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False)
+    else:
+        solver.load_const(f["phi"], f["rhs"], f["lam"], f["Dc"])
+    t_stage = time.perf_counter() - t_stage
+
+    st = solver.iterate(args.warmup) if args.warmup > 0 else 0
+    s0 = solver.stats()
+    k_ms0 = list(s0.kernel_ms)
+    k_n0 = list(s0.kernel_calls)
+
+    barrier()
+    t0 = time.perf_counter()
+    st = solver.iterate(args.steps)          # returns after a stream synchronise
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    s1 = solver.stats()
+    hist = solver.history()
+    ok = (st == 0 and s1.iterations == args.warmup + args.steps and np.all(np.isfinite(hist)))
+
+    if rank == 0:
+        npts = float(n + 1) ** 3
+        words = kernel_words(L, var, False)
+        kern = {}
+        for k, w in words.items():
+            calls = s1.kernel_calls[k] - k_n0[k]
+            ms = s1.kernel_ms[k] - k_ms0[k]
+            if calls > 0:
+                kern[k] = dict(name=KIND_NAMES[k], calls=calls, avg_ms=ms / calls, words=w,
+                               gbs=8.0 * w * npts / world / (ms / calls * 1e-3) / 1e9)
+        dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["calls"]) if kern else None
+        roof = None
+        if dom is not None:
+            roof = {"bound": "hbm", "kernel": kern[dom]["name"], "achieved": round(kern[dom]["gbs"], 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(kern[dom]["avg_ms"], 4),
+                    "algorithmic_bytes_per_launch": 8.0 * kern[dom]["words"] * npts / world}
+        ms_step = elapsed / args.steps * 1e3
+        W = {1: (26 if var else 20), 2: (62 if var else 50)}[L]
+        whole = 8.0 * W * npts / (ms_step * 1e-3) / 1e9
+        out = {
+            "metric": "BiCGStab iters/sec + achieved HBM GB/s (fp64 512^3) at 1/2/4/8 MI355X",
+            "value": round(args.steps / elapsed, 3), "unit": "iter/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%d^3 fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), Dirichlet faces, "
+                                   "%d z-slab(s)" % (n, "variable" if var else "constant", L, world),
+                       "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world},
+            "valid": bool(ok),
+            "iteration_GBps": round(whole, 1),
+            "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),
+            "iteration_words_per_point": W,
+            "stage_s": round(t_stage, 3),
+            "residual_after": float(hist[-1]) if len(hist) else None,
+            "kernels": {v["name"]: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["gbs"], 1),
+                                    "words": v["words"], "calls": v["calls"]} for v in kern.values()},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, L, args.workload, n, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,151 @@
+/*
+ * krylov_amd.h -- C ABI of the MI355X BiCGStab(l) stencil solver.
+ *
+ * Plain C types only.  Every entry point names the reference interface it
+ * stands in for (paths relative to the reference tree).
+ *
+ * Host field layout (what the reference's NumMatrix<double,3> fields hold):
+ * ghost-inclusive box [-1 .. m+1] per direction, x fastest, no padding:
+ *   index(i,j,k) = ((k+1)*(my+3) + (j+1))*(mx+3) + (i+1).
+ * The library copies host fields into its own padded device layout and never
+ * keeps a host pointer after a call returns.
+ *
+ * Domain decomposition: z slabs that share their interface plane, as
+ * mpi_manager_3D::make_LocalGrid does for direction 2
+ * (BICGStab3D/mpi_manager.C:342-408): with `nslabs` slabs every slab has
+ * mz_local = mz_global / nslabs and plane mz_local of slab s is plane 0 of
+ * slab s+1.  A process owns `slab_count` consecutive slabs starting at
+ * `slab_begin` (one per device in `devices`), and the host fields it passes
+ * cover exactly those slabs: mz_host = slab_count * mz_local.
+ */
+#ifndef KRYLOV_AMD_H
+#define KRYLOV_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KRY_MAX_L        8
+#define KRY_MAX_SLABS    16
+#define KRY_UID_BYTES    128
+
+/* status codes (the reference prints and calls exit(); see kry_solve_*) */
+enum {
+	KRY_OK            = 0,
+	KRY_NAN_ALPHA     = 1,   /* BICGStab3D/solveLin_BICGStab.C:406-409, exit(1) */
+	KRY_NAN_NORM      = 3,   /* BICGStab3D/solveLin_BICGStab.C:491-494, exit(3) */
+	KRY_MAX_ITER      = 4,   /* stopped by max_outer (no counterpart: the reference has no cap) */
+	KRY_ERR_ARG       = -1,
+	KRY_ERR_HIP       = -2,
+	KRY_ERR_COMM      = -3,
+	KRY_ERR_STATE     = -4
+};
+
+/* flags */
+enum {
+	KRY_FORCE_GENERIC = 1,   /* run the one-kernel-per-primitive path even when the fused path applies */
+	KRY_NO_GRAPH      = 2    /* reserved */
+};
+
+typedef struct kry_desc {
+	int    mx[3];          /* last grid-point index of the host fields, per direction
+	                          (grid_1D::get_mx, BICGStab3D/solveLin_BICGStab.C:165-167) */
+	double delx[3];        /* grid spacing (grid_1D::get_del, solveLin_BICGStab.C:161-163) */
+	int    bc_type[6];     /* xlo,xhi,ylo,yhi,zlo,zhi of the GLOBAL domain: 0 Dirichlet,
+	                          1 linear extrapolation ("Neumann"), other: untouched
+	                          (BoundaryHandler::bc_Type, BICGStab3D/BoundaryHandler.C:49-91) */
+	int    L;              /* solverPars(0), solveLin_BICGStab.C:150 */
+	double eps;            /* epsilon_, solveLin_BICGStab.C:149 */
+	int    max_outer;      /* 0 = unlimited */
+	int    flags;
+	int    nslabs;         /* global number of z slabs (>= 1) */
+	int    slab_begin;     /* first slab owned by this process */
+	int    slab_count;     /* slabs owned by this process (>= 1) */
+	int    devices[KRY_MAX_SLABS]; /* HIP device ordinal per owned slab */
+} kry_desc;
+
+typedef struct kry_stats {
+	int    status;
+	int    iterations;       /* outer iterations executed by the last solve/iterate */
+	int    fused;            /* 1: fused Dirichlet path, 0: generic path */
+	double norm_rhs;
+	double norm_init;
+	double norm_final;
+	double solve_ms;         /* device time of the iteration loop (HIP events) */
+	double stage_ms;         /* host<->device staging + prologue */
+	double bytes_per_iter;   /* algorithmic bytes: 8 * W * N_pts of the global grid */
+	double kernel_ms[8];     /* HIP-event time per fused kernel kind, summed over calls */
+	int    kernel_calls[8];
+} kry_stats;
+
+typedef struct kry_solver *kry_handle;
+
+/* Replaces BICGStab::BICGStab / BICGStab::setup + make_Arrays
+ * (BICGStab3D/solveLin_BICGStab.C:104-191): fixes geometry, l and eps and
+ * allocates the work vectors on the device(s). */
+kry_handle kry_create(const kry_desc *desc, int *status);
+void       kry_destroy(kry_handle h);
+
+/* Inter-process communicator for slabs owned by other processes; the analogue
+ * of handing mpi_manager_3D::comm3d to the solver
+ * (BICGStab3D/solveLin_BICGStab.C:142-147).  Rank r must own slab r.  The id
+ * comes from kry_comm_unique_id on one rank and is distributed by the caller
+ * (MPI_Bcast, a torch.distributed store, ...). */
+int kry_comm_unique_id(void *uid /* KRY_UID_BYTES */);
+int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks);
+
+/* Replaces BICGStab::solve(bounds, phi, rhs, lambda, D_xx, D_yy, D_zz, debug)
+ * (BICGStab3D/solveLin_BICGStab.C:200-215).  phi: initial guess in, solution
+ * out.  Returns a status instead of calling exit(). */
+int kry_solve_const(kry_handle h, double *phi, const double *rhs, const double *lambda,
+                    double Dxx, double Dyy, double Dzz, int debug);
+
+/* Replaces BICGStab::solve(bounds, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy, debug,
+ * use_offDiagDiffusion) (BICGStab3D/solveLin_BICGStab.C:218-236).  With
+ * use_offdiag == 0 the solver treats Dxy as zero; Dxy may then be NULL.  (The
+ * reference clears the caller's Dxy array; the C++ adaptor does that.) */
+int kry_solve_var(kry_handle h, double *phi, const double *rhs, const double *lambda,
+                  const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy,
+                  int use_offdiag, int debug);
+
+/* Device-resident stepping (no counterpart in the reference, which always
+ * solves to convergence): kry_load_* stages the fields and runs the prologue of
+ * solve_int (solveLin_BICGStab.C:268-320); kry_iterate runs up to n_outer passes
+ * of the do{}while body (solveLin_BICGStab.C:327-496) and stops early on
+ * convergence or failure; kry_fetch_phi copies the current solution back. */
+int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda,
+                   double Dxx, double Dyy, double Dzz);
+int kry_load_var(kry_handle h, const double *phi, const double *rhs, const double *lambda,
+                 const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy,
+                 int use_offdiag);
+int kry_iterate(kry_handle h, int n_outer);
+int kry_fetch_phi(kry_handle h, double *phi);
+
+int kry_get_stats(kry_handle h, kry_stats *out);
+/* `norm` of every outer iteration (solveLin_BICGStab.C:464); returns the count. */
+int kry_get_history(kry_handle h, double *norms, int cap);
+
+/* Single operators on host fields, for kernel-level checks.  They run the same
+ * device kernels the solver uses.
+ *   kry_op_do_bcs   : BoundaryHandler3D::do_BCs(dist, 1)   BICGStab3D/BoundaryHandler.C:370-575
+ *   kry_op_spmv_*   : Krylov::multiply_withMat              BICGStab3D/Krylov.C:500-541 / 407-496
+ *   kry_op_dot      : Krylov::dot_product                   BICGStab3D/Krylov.C:161-244
+ *   kry_op_l2norm   : Krylov::get_l2Norm                    BICGStab3D/Krylov.C:36-157
+ * `fused` selects the LDS-tiled Dirichlet kernel (requires all faces Dirichlet)
+ * instead of the generic one. */
+int kry_op_do_bcs(kry_handle h, double *field);
+int kry_op_spmv_const(kry_handle h, double *psi, const double *lambda, double Dxx, double Dyy,
+                      double Dzz, double *out, int apply_bcs, int fused);
+int kry_op_spmv_var(kry_handle h, const double *psi, const double *lambda, const double *Dxx,
+                    const double *Dyy, const double *Dzz, const double *Dxy, int use_offdiag,
+                    double *out, int apply_bcs, int fused);
+int kry_op_dot(kry_handle h, const double *a, const double *b, double *result);
+int kry_op_l2norm(kry_handle h, const double *v, double *result);
+
+const char *kry_status_string(int status);
+const char *kry_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+#include "kry_comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+namespace {
+
+struct Api {
+	void *lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Api g_api;
+std::mutex g_mu;
+thread_local std::string g_cerr;
+
+template <class F> bool sym(F &f, const char *name)
+{
+	f = reinterpret_cast<F>(dlsym(g_api.lib, name));
+	return f != nullptr;
+}
+
+// The ROCm installation's library is preferred over one a Python package may
+// have mapped already under the same soname.
+bool load_api()
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (g_api.lib) return true;
+	const char *cands[] = {getenv("KRY_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+	for (const char *c : cands) {
+		if (!c || !*c) continue;
+		g_api.lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+		if (g_api.lib) break;
+	}
+	if (!g_api.lib) { g_cerr = std::string("cannot open librccl: ") + dlerror(); return false; }
+	bool ok = sym(g_api.GetUniqueId, "ncclGetUniqueId") && sym(g_api.CommInitRank, "ncclCommInitRank") &&
+	          sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.AllReduce, "ncclAllReduce") &&
+	          sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") && sym(g_api.GroupStart, "ncclGroupStart") &&
+	          sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.GetErrorString, "ncclGetErrorString");
+	if (!ok) { g_cerr = "librccl lacks a required symbol"; dlclose(g_api.lib); g_api.lib = nullptr; }
+	return ok;
+}
+
+int fail(const char *what, ncclResult_t r)
+{
+	g_cerr = std::string(what) + ": " + (g_api.GetErrorString ? g_api.GetErrorString(r) : "?");
+	return -3;   // KRY_ERR_COMM
+}
+
+#define NCHK(call)                                 \
+	do {                                           \
+		ncclResult_t r_ = (call);                  \
+		if (r_ != ncclSuccess) return fail(#call, r_); \
+	} while (0)
+
+} // namespace
+
+const char *KryComm::last_error() { return g_cerr.c_str(); }
+
+int KryComm::unique_id(void *uid)
+{
+	if (!uid) return -1;
+	if (!load_api()) return -3;
+	ncclUniqueId id;
+	NCHK(g_api.GetUniqueId(&id));
+	static_assert(sizeof(id) == 128, "unique id size");
+	memcpy(uid, &id, sizeof id);
+	return 0;
+}
+
+int KryComm::init(const void *uid, int rank, int nranks)
+{
+	if (comm_) return 0;
+	if (!load_api()) return -3;
+	ncclUniqueId id;
+	memcpy(&id, uid, sizeof id);
+	ncclComm_t c = nullptr;
+	NCHK(g_api.CommInitRank(&c, nranks, id, rank));
+	comm_ = c;
+	rank_ = rank;
+	nranks_ = nranks;
+	return 0;
+}
+
+void KryComm::destroy()
+{
+	if (comm_ && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(comm_));
+	comm_ = nullptr;
+}
+
+int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
+{
+	NCHK(g_api.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, static_cast<ncclComm_t>(comm_), st));
+	return 0;
+}
+
+int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_hi, const double *send_hi,
+                  double *recv_hi, size_t count, hipStream_t st)
+{
+	if (peer_lo < 0 && peer_hi < 0) return 0;
+	ncclComm_t c = static_cast<ncclComm_t>(comm_);
+	NCHK(g_api.GroupStart());
+	if (peer_lo >= 0) {
+		NCHK(g_api.Send(send_lo, count, ncclDouble, peer_lo, c, st));
+		NCHK(g_api.Recv(recv_lo, count, ncclDouble, peer_lo, c, st));
+	}
+	if (peer_hi >= 0) {
+		NCHK(g_api.Send(send_hi, count, ncclDouble, peer_hi, c, st));
+		NCHK(g_api.Recv(recv_hi, count, ncclDouble, peer_hi, c, st));
+	}
+	NCHK(g_api.GroupEnd());
+	return 0;
+}

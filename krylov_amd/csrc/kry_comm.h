@@ -1,0 +1,31 @@
+// Inter-process exchange for z slabs owned by other processes: RCCL over xGMI.
+// librccl is opened at run time (kry_comm_init), so a single-process solve
+// needs no communication library at all.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+class KryComm {
+public:
+	// 128-byte id created on one rank and handed to every rank's init()
+	static int unique_id(void *uid);
+	static const char *last_error();
+
+	int init(const void *uid, int rank, int nranks);
+	void destroy();
+	bool active() const { return comm_ != nullptr; }
+	int rank() const { return rank_; }
+	int nranks() const { return nranks_; }
+
+	// in-place sum of n doubles over all ranks, queued on `st`
+	int allreduce_sum(double *buf, int n, hipStream_t st);
+	// send `count` doubles to / receive from the lower and upper neighbour
+	// (peer < 0: no neighbour on that side), one grouped call queued on `st`
+	int halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_hi, const double *send_hi,
+	         double *recv_hi, size_t count, hipStream_t st);
+
+private:
+	void *comm_ = nullptr;
+	int rank_ = 0, nranks_ = 1;
+};

@@ -1,0 +1,72 @@
+// Kernel argument blocks and launch wrappers (implemented in kry_kernels.hip).
+#pragma once
+
+#include "kry_device.h"
+
+#define KRY_TXW 128   // fused tile width in grid points
+#define KRY_SEG 2048  // doubles of a plane handled per block and plane by the streaming kernels
+
+// fused stencil kernel kinds
+enum KryFusedKind {
+	KF_A0 = 0,   // u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
+	KF_A1,       // l=2, jj=1: phi += alpha*u0 ; u0 = r0 - beta*u0 ; u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
+	KF_B0,       // l=2, jj=0: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
+	KF_B0L,      // l=1:       r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
+	KF_B1L,      // l=2, jj=1: r0 -= alpha*u1 ; r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0,r1), (r2,r1)
+	KF_RES,      // r0 = r~ = rhs - A phi ; |r0|^2
+	KF_SPMV,     // out = A psi
+	KF_NKINDS
+};
+
+// grid reduction bookkeeping
+struct KryRed {
+	double *partial;     // nblk * ND doubles
+	unsigned *counter;   // ticket counter, zero between launches
+	KryState *S;
+	int nblk;
+	int phase;           // KryPhase run by the last block when S->local_scalars
+};
+
+struct KryFused {
+	KryGeo g;
+	KryOp op;
+	KryState *S;
+	const double *X, *Y;     // psi = X + Y*c  (c = -beta for A kinds, -alpha for B kinds)
+	double *Xout;            // where psi is stored (ping-pong partner of X's role)
+	double *O, *O2;          // stencil output (O2: second copy, KF_RES only)
+	const double *lam, *Dxx, *Dyy, *Dzz, *Dxy;
+	const double *RT, *RHS;
+	double *phi, *E;         // pointwise companions (KF_A1: phi, E = u0; KF_B1L: E = r0)
+	const double *Ea;        //                      (KF_A1: r0;          KF_B1L: u1)
+	KryRed red;
+	int zlo, zhi;            // planes on which the stencil is evaluated
+	int zc;                  // planes per chunk
+	int ntx, nty, nchunk, nblk;
+};
+
+#define KRY_STREAM_MAXV (2 * KRY_LMAX + 3)
+struct KryStream {
+	KryGeo g;
+	KryState *S;
+	const double *v[8];      // read-only operands
+	double *w[4];            // in/out operands
+	KryRed red;
+	int zfirst;              // first plane processed
+	int nplanes;             // planes processed, strided over blockIdx.y
+	int cnt_lo, cnt_hi;      // planes that count in the dot products
+};
+
+hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact,
+                            hipStream_t st);
+hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);
+hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st);
+hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st);
+hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, hipStream_t st);
+hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st);
+hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
+hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st);
+hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,
+                            const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
+                            const double *Dxy, double *out, hipStream_t st);
+hipError_t kry_launch_wdot(const KryGeo &g, const double *x, const double *y, int norm_mode, KryRed red,
+                           hipStream_t st);

@@ -1,0 +1,898 @@
+// gfx950 kernels of the BiCGStab(l) stencil solver.
+//
+// Two families:
+//   * fused Dirichlet kernels (k_fused, k_final, k_mgs2): LDS-tiled, z-marching
+//     stencil fused with the vector update that produces its input and with the
+//     dot products that consume its output; wave64 shuffles + a single-pass grid
+//     reduction whose last block also advances the scalar recurrences.
+//   * generic kernels (g_*): one kernel per primitive, any face type, used for
+//     Neumann / mixed boundaries, for l > 2 and as an independent cross-check.
+//
+// The translation unit is built with -ffp-contract=off: every product and sum
+// below rounds separately, in the order the reference evaluates them
+// (BICGStab3D/Krylov.C:434-456, 524-530; BICGStab3D/solveLin_BICGStab.C:356-462),
+// so results differ from a CPU evaluation only through summation order in dots.
+#include "kry_kernels.h"
+
+#include <math.h>
+
+#define NT 256                 // threads per block in every kernel here
+#define NW (NT / 64)           // wavefronts per block
+#define TXW KRY_TXW            // tile width in grid points = one 1 KiB wave load of double2
+#define SEG2 1024               // double2 elements of a plane segment handled per block and plane
+#define LW 132                 // LDS row pitch: col 1 = left halo, 2..129 = tile, 130 = right halo
+
+// ---------------------------------------------------------------------------
+// scalar recurrences (solveLin_BICGStab.C:341-352, 390, 406-409, 419-446, 464-496)
+// ---------------------------------------------------------------------------
+__device__ inline bool really_is_nan(double xd)
+{
+	// Krylov::reallyIsNan(float), Krylov.C:553-559: narrows to float first.
+	float x = (float)xd;
+	return (__float_as_uint(x) & 0x7F800000u) == 0x7F800000u;
+}
+
+__device__ void kry_scalar_step(KryState *S, int phase)
+{
+	const double *s = S->sums;
+	switch (phase) {
+	case PH_INIT: {
+		double n = sqrt(s[0]);
+		S->norm_init = n;
+		S->norm = 1.e99;
+		S->iter = 0;
+		S->status = 0;
+		S->done = 0;
+		if (n < S->eps * S->norm_rhs) {           // :303-311, no iterations
+			S->norm = n;
+			S->done = 1;
+			break;
+		}
+		// :317-320 then the head of the first pass (:341, :349-352, jj = 0)
+		double rho0 = 1., alpha = 0., omega = 1.;
+		rho0 = rho0 * (-omega);
+		double rho1 = s[0];                       // (r0, r~) with r~ = r0
+		S->beta = alpha * rho1 / rho0;
+		S->rho0 = rho1;
+		S->rho1 = rho1;
+		S->alpha = alpha;
+		S->omega = omega;
+		break;
+	}
+	case PH_A:
+		S->alpha = S->rho0 / s[0];                // :390
+		break;
+	case PH_B: {
+		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; break; }   // :406-409
+		double rho1 = s[0];                       // :349 of the next jj
+		S->beta = S->alpha * rho1 / S->rho0;      // :351
+		S->rho0 = rho1;
+		S->rho1 = rho1;
+		break;
+	}
+	case PH_BL1:
+		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; break; }
+		S->sigma[1] = s[1];                       // :427
+		S->gammap[1] = s[0] / S->sigma[1];        // :428
+		S->omega = S->gamma[1] = S->gammap[1];    // :431
+		break;
+	case PH_BL2:
+		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; break; }
+		S->sigma[1] = s[0];
+		S->gammap[1] = s[1] / S->sigma[1];
+		S->tau[1][2] = s[2] / S->sigma[1];        // :422
+		break;
+	case PH_M2:
+		S->sigma[2] = s[0];
+		S->gammap[2] = s[1] / S->sigma[2];
+		S->omega = S->gamma[2] = S->gammap[2];
+		S->gamma[1] = S->gammap[1] - S->tau[1][2] * S->gamma[2];   // :434-439
+		S->gammapp[1] = S->gamma[2];                                // :441-446
+		break;
+	case PH_F: {
+		double norm = sqrt(s[0]);                 // :464 (unscaled single pass)
+		S->norm = norm;
+		if (S->iter < KRY_HIST_CAP) S->hist[S->iter] = norm;
+		S->iter += 1;
+		if (really_is_nan(norm)) { S->status = 3; S->done = 1; break; }      // :491-494
+		if (!(norm > S->eps * S->norm_rhs)) { S->done = 1; break; }           // :496
+		if (S->max_outer > 0 && S->iter >= S->max_outer) { S->status = 4; S->done = 1; break; }
+		double rho0 = S->rho0 * (-S->omega);      // :341
+		double rho1 = s[1];                       // :349, jj = 0
+		S->beta = S->alpha * rho1 / rho0;
+		S->rho0 = rho1;
+		S->rho1 = rho1;
+		break;
+	}
+	default: break;
+	}
+}
+
+__global__ void k_scalar(KryState *S, int phase)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		if (S->done && phase != PH_INIT) return;
+		kry_scalar_step(S, phase);
+	}
+}
+
+// total of the per-slab sums, added in slab order
+__global__ void k_sum_slabs(const double *gather, int nslabs, double *out)
+{
+	const int k = threadIdx.x;
+	if (k >= KRY_NSUMS) return;
+	double v = gather[k];
+	for (int s = 1; s < nslabs; ++s) v += gather[s * KRY_NSUMS + k];
+	out[k] = v;
+}
+
+// ---------------------------------------------------------------------------
+// block reduction + single-pass grid reduction
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+// Every block deposits ND partial sums; the block that draws the last ticket
+// adds all partials in a fixed order (so the result does not depend on which
+// block that is), publishes them in S->sums and, when the solver runs on one
+// slab, advances the scalar recurrences.  The partials travel between blocks
+// as agent-scope (write-through / cache-bypassing) stores and loads, so no
+// cache write-back or invalidate is needed around the ticket: stores, vmcnt
+// drain, barrier, relaxed agent-scope ticket; the last block reads every
+// partial with agent-scope loads.
+__device__ inline void pub_store(double *p, double v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double pub_load(const double *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int ND>
+__device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r)
+{
+	const long bid = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+	__shared__ double red[NW][ND];
+	__shared__ int is_last;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+#pragma unroll
+	for (int k = 0; k < ND; ++k) {
+		double v = wave_sum(acc[k]);
+		if (lane == 0) red[w][k] = v;
+	}
+	__syncthreads();
+	if (tid < ND) {
+		double v = red[0][tid];
+#pragma unroll
+		for (int i = 1; i < NW; ++i) v += red[i][tid];
+		pub_store(&r.partial[bid * ND + tid], v);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (tid == 0) {
+		unsigned t = __hip_atomic_fetch_add(r.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		is_last = (t == (unsigned)r.nblk - 1u);
+	}
+	__syncthreads();
+	if (!is_last) return;
+
+	double tot[ND];
+#pragma unroll
+	for (int k = 0; k < ND; ++k) tot[k] = 0.;
+	for (int b = tid; b < r.nblk; b += NT) {
+#pragma unroll
+		for (int k = 0; k < ND; ++k) tot[k] += pub_load(&r.partial[(long)b * ND + k]);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < ND; ++k) {
+		double v = wave_sum(tot[k]);
+		if (lane == 0) red[w][k] = v;
+	}
+	__syncthreads();
+	if (tid == 0) {
+#pragma unroll
+		for (int k = 0; k < ND; ++k) {
+			double v = red[0][k];
+#pragma unroll
+			for (int i = 1; i < NW; ++i) v += red[i][k];
+			r.S->sums[k] = v;
+		}
+		__hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (r.S->local_scalars && r.phase != PH_NONE) kry_scalar_step(r.S, r.phase);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// fused stencil kernel
+// ---------------------------------------------------------------------------
+__device__ inline double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ inline void st2(double *p, double2 v) { *reinterpret_cast<double2 *>(p) = v; }
+__device__ inline double2 axpy2(double2 x, double2 y, double c)
+{
+	// x + (y*c): product rounded, then sum rounded (solveLin_BICGStab.C:358-360, 393)
+	double2 t;
+	t.x = y.x * c;
+	t.y = y.y * c;
+	t.x = x.x + t.x;
+	t.y = x.y + t.y;
+	return t;
+}
+__device__ inline double axpy1(double x, double y, double c)
+{
+	double t = y * c;
+	return x + t;
+}
+
+template <bool EXACT>
+__device__ inline double div2d(double v, double two_d, double inv_two_d)
+{
+	if (EXACT) return v * inv_two_d;   // two_d is a power of two: identical rounding
+	return v / two_d;
+}
+
+// One output value of the operator at a point.
+//   p*: psi at the point and its neighbours; VAR adds coefficient fields.
+struct Sten {
+	double pc, xm, xp, ym, yp, zm, zp;
+	double pmm, pmp, ppm, ppp;              // psi(x-1,y-1), (x-1,y+1), (x+1,y-1), (x+1,y+1)
+	double lam;
+	double dxx, dyy, dzz, dxy;
+	double dxx_m, dxx_p, dyy_m, dyy_p, dzz_m, dzz_p;
+	double dxy_xm, dxy_xp, dxy_ym, dxy_yp;
+};
+
+template <bool VAR, bool OFFD, bool EXACT>
+__device__ inline double apply_op(const Sten &s, const KryOp &op)
+{
+	if (!VAR) {
+		// Krylov.C:524-530
+		double a = op.c[0] * (s.xp + s.xm);
+		double b = op.c[1] * (s.yp + s.ym);
+		double c = op.c[2] * (s.zp + s.zm);
+		double d = (op.cd2 + s.lam) * s.pc;
+		return ((a + b) + c) - d;
+	} else {
+		// Krylov.C:434-456, summed left to right
+		double cx = op.c[0] * s.dxx, cy = op.c[1] * s.dyy, cz = op.c[2] * s.dzz;
+		double t1 = cx * (s.xp + s.xm);
+		double t2 = cy * (s.yp + s.ym);
+		double t3 = cz * (s.zp + s.zm);
+		double t4 = (2. * ((cx + cy) + cz) + s.lam) * s.pc;
+		double acc = ((t1 + t2) + t3) - t4;
+		double gx = div2d<EXACT>(s.dxx_p - s.dxx_m, op.two_d[0], op.inv_two_d[0]);
+		double gy = div2d<EXACT>(s.dyy_p - s.dyy_m, op.two_d[1], op.inv_two_d[1]);
+		if (OFFD) {
+			double t5 = (op.cxy * s.dxy) * (((s.ppp - s.ppm) - s.pmp) + s.pmm);
+			acc = acc + t5;
+			gx = gx + div2d<EXACT>(s.dxy_yp - s.dxy_ym, op.two_d[1], op.inv_two_d[1]);
+			gy = div2d<EXACT>(s.dxy_xp - s.dxy_xm, op.two_d[0], op.inv_two_d[0]) + gy;
+		}
+		double t6 = div2d<EXACT>(gx * (s.xp - s.xm), op.two_d[0], op.inv_two_d[0]);
+		double t7 = div2d<EXACT>(gy * (s.yp - s.ym), op.two_d[1], op.inv_two_d[1]);
+		double gz = div2d<EXACT>(s.dzz_p - s.dzz_m, op.two_d[2], op.inv_two_d[2]);
+		double t8 = div2d<EXACT>(gz * (s.zp - s.zm), op.two_d[2], op.inv_two_d[2]);
+		return ((acc + t6) + t7) + t8;
+	}
+}
+
+template <int KIND> struct KindTraits;
+template <> struct KindTraits<KF_A0>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_A1>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_B0>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_B0L>  { static constexpr int ND = 2; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_B1L>  { static constexpr int ND = 3; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_RES>  { static constexpr int ND = 1; static constexpr bool UPD = false; };
+template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static constexpr bool UPD = false; };
+
+// Tile: TXW points in x (one double2 per lane), TY rows, marched over a chunk of
+// planes.  psi of plane z lives in LDS buffer z&1 (tile + one halo ring), psi of
+// planes z-1, z, z+1 at the thread's own points lives in registers.
+template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT>
+__global__ __launch_bounds__(NT) void k_fused(const KryFused a)
+{
+	constexpr int VD = TY / NW;                 // rows per thread
+	constexpr int ND = KindTraits<KIND>::ND;
+	constexpr bool UPD = KindTraits<KIND>::UPD; // psi = X + Y*c and is stored to Xout
+	constexpr bool IS_A = (KIND == KF_A0 || KIND == KF_A1);
+	__shared__ __align__(16) double lds[2][(TY + 2) * LW];
+
+	const KryGeo &g = a.g;
+	KryState *S = a.S;
+	if (KIND != KF_SPMV && KIND != KF_RES && S->done) return;
+
+	const double cpsi = UPD ? (IS_A ? -S->beta : -S->alpha) : 0.;
+	const double alpha_prev = (KIND == KF_A1) ? S->alpha : 0.;
+
+	// XCD-aware block -> tile map: blocks that share blockIdx%8 get neighbouring tiles
+	int bid;
+	{
+		const int nb = a.nblk, b = blockIdx.x;
+		const int q = nb >> 3, r = nb & 7, x = b & 7;
+		bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+	}
+	const int tx = bid % a.ntx;
+	const int ty = (bid / a.ntx) % a.nty;
+	const int ch = bid / (a.ntx * a.nty);
+
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int z0 = a.zlo + ch * a.zc;
+	const int z1 = min(z0 + a.zc, a.zhi + 1);   // exclusive
+	const int y0 = ty * TY;                     // first row (grid index j) of the tile
+	const int c0 = 2 + tx * TXW;                // first column of the tile
+	const int col = c0 + 2 * lane;              // column of .x ; grid index i = col - 2
+	const int ix = col - 2;
+	const bool mxx = (ix >= 1 && ix <= g.mx - 1);
+	const bool mxy = (ix + 1 >= 1 && ix + 1 <= g.mx - 1);
+
+	long off[VD];        // in-plane offset of the own double2
+	int lidx[VD];        // LDS index of the own double2
+	bool mrow[VD];
+#pragma unroll
+	for (int e = 0; e < VD; ++e) {
+		const int r = w * VD + e;
+		const int j = y0 + r;
+		off[e] = (long)(j + 1) * g.px + col;
+		lidx[e] = (r + 1) * LW + 2 + 2 * lane;
+		mrow[e] = (j >= 1 && j <= g.my - 1);
+	}
+	// halo duties: waves 0,1 load the row above / below the tile, wave 2 the two columns
+	const bool hrow = tid < 128;
+	const int hr = tid >> 6;                                    // 0: row -1, 1: row TY
+	const long hoff = (long)(y0 + (hr ? TY : -1) + 1) * g.px + col;
+	const int hl = (hr ? TY + 1 : 0) * LW + 2 + 2 * lane;
+	const int cidx = tid - 128;
+	const bool hcol = (cidx >= 0 && cidx < 2 * (TY + 2));
+	const int crr = cidx >> 1, cside = cidx & 1;
+	const long coff = (long)(y0 + crr - 1 + 1) * g.px + (cside ? c0 + TXW : c0 - 1);
+	const int cl = crr * LW + (cside ? 130 : 1);
+
+	double2 pm[VD], pc[VD], pp[VD];
+	double2 dzm[VD], dzc[VD], dzp[VD];
+	double2 nx[VD], ny[VD];
+	double2 hx = {0., 0.}, hy = {0., 0.};
+	double sx = 0., sy = 0.;
+	double acc[ND];
+#pragma unroll
+	for (int k = 0; k < ND; ++k) acc[k] = 0.;
+
+	auto plane = [&](int z) -> long { return (long)(z + 1) * g.ps; };
+
+	// issue the loads that psi of plane z needs (own points and halo ring)
+	auto issue = [&](int z) {
+		const long pb = plane(z);
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			nx[e] = ld2(a.X + pb + off[e]);
+			if (UPD) ny[e] = ld2(a.Y + pb + off[e]);
+		}
+		if (hrow) {
+			hx = ld2(a.X + pb + hoff);
+			if (UPD) hy = ld2(a.Y + pb + hoff);
+		}
+		if (hcol) {
+			sx = a.X[pb + coff];
+			if (UPD) sy = a.Y[pb + coff];
+		}
+	};
+	// psi of the issued plane at the own points
+	auto own_psi = [&](double2 (&dst)[VD]) {
+#pragma unroll
+		for (int e = 0; e < VD; ++e) dst[e] = UPD ? axpy2(nx[e], ny[e], cpsi) : nx[e];
+	};
+	// write psi (own + halo) of the issued plane into an LDS buffer
+	auto to_lds = [&](const double2 (&v)[VD], double *buf) {
+#pragma unroll
+		for (int e = 0; e < VD; ++e) st2(buf + lidx[e], v[e]);
+		if (hrow) st2(buf + hl, UPD ? axpy2(hx, hy, cpsi) : hx);
+		if (hcol) buf[cl] = UPD ? axpy1(sx, sy, cpsi) : sx;
+	};
+	// store psi to its ping-pong partner at interior points of plane z
+	auto store_psi = [&](const double2 (&v)[VD], int z) {
+		if (!UPD) return;
+		const long pb = plane(z);
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			if (mrow[e]) {
+				if (mxx && mxy) st2(a.Xout + pb + off[e], v[e]);
+				else if (mxx) a.Xout[pb + off[e]] = v[e].x;
+				else if (mxy) a.Xout[pb + off[e] + 1] = v[e].y;
+			}
+		}
+	};
+	// pointwise companions of plane z; returns the updated companion for dots
+	auto extras = [&](int z, int e, double2 &comp) {
+		const long p = plane(z) + off[e];
+		if (KIND == KF_A1) {
+			// phi += u0*alpha (solveLin_BICGStab.C:403, deferred from jj = 0), then
+			// u0 = r0 - beta*u0 (:356-362, ii = 0 of jj = 1)
+			double2 u0 = ld2(a.E + p), r0 = ld2(a.Ea + p), ph = ld2(a.phi + p);
+			ph = axpy2(ph, u0, alpha_prev);
+			double2 un = axpy2(r0, u0, cpsi);
+			if (mrow[e]) {
+				if (mxx && mxy) { st2(a.phi + p, ph); st2(a.E + p, un); }
+				else if (mxx) { a.phi[p] = ph.x; a.E[p] = un.x; }
+				else if (mxy) { a.phi[p + 1] = ph.y; a.E[p + 1] = un.y; }
+			}
+			comp = un;
+		} else if (KIND == KF_B1L) {
+			// r0 -= alpha*u1 (:392-394, ii = 0 of jj = 1)
+			double2 r0 = ld2(a.E + p), u1 = ld2(a.Ea + p);
+			double2 rn = axpy2(r0, u1, cpsi);
+			if (mrow[e]) {
+				if (mxx && mxy) st2(a.E + p, rn);
+				else if (mxx) a.E[p] = rn.x;
+				else if (mxy) a.E[p + 1] = rn.y;
+			}
+			comp = rn;
+		}
+	};
+
+	// ---- prologue: planes z0-1, z0 and the loads of z0+1 ----
+	issue(z0 - 1);
+	own_psi(pm);
+	if (VAR) {
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			dzm[e] = ld2(a.Dzz + plane(z0 - 1) + off[e]);
+			dzc[e] = ld2(a.Dzz + plane(z0) + off[e]);
+		}
+	}
+	if (z0 == a.zlo && g.has_lo && z0 == 0) {   // plane -1 belongs to a neighbour: keep its ghosts current
+		store_psi(pm, -1);
+		if (KIND == KF_A1 || KIND == KF_B1L) {
+#pragma unroll
+			for (int e = 0; e < VD; ++e) { double2 d; extras(-1, e, d); }
+		}
+	}
+	issue(z0);
+	own_psi(pc);
+	to_lds(pc, lds[z0 & 1]);
+	store_psi(pc, z0);
+	issue(z0 + 1);
+	__syncthreads();
+
+	for (int z = z0; z < z1; ++z) {
+		// 1. psi of plane z+1 -> registers, other LDS buffer, memory
+		own_psi(pp);
+		to_lds(pp, lds[(z + 1) & 1]);
+		if (z + 1 < z1 || (z + 1 == a.zhi + 1 && g.has_hi && a.zhi == g.mz)) store_psi(pp, z + 1);
+		// 2. prefetch the inputs of plane z+2
+		if (z + 1 < z1) issue(z + 2);
+
+		// 3. stencil on plane z
+		const long pb = plane(z);
+		const double *buf = lds[z & 1];
+		const bool cnt = (z >= 1);               // plane 0 is a Dirichlet face or counted by the lower slab
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			const long p = pb + off[e];
+			const int li = lidx[e];
+			Sten s0, s1;
+			const double2 lam = ld2(a.lam + p);
+			const double xl = buf[li - 1], xr = buf[li + 2];
+			const double2 ym = ld2(buf + li - LW), yp = ld2(buf + li + LW);
+			s0.pc = pc[e].x; s1.pc = pc[e].y;
+			s0.xm = xl;      s0.xp = pc[e].y;
+			s1.xm = pc[e].x; s1.xp = xr;
+			s0.ym = ym.x; s1.ym = ym.y; s0.yp = yp.x; s1.yp = yp.y;
+			s0.zm = pm[e].x; s1.zm = pm[e].y; s0.zp = pp[e].x; s1.zp = pp[e].y;
+			s0.lam = lam.x; s1.lam = lam.y;
+			if (VAR) {
+				const double2 dxx = ld2(a.Dxx + p), dyy = ld2(a.Dyy + p);
+				const double dxl = a.Dxx[p - 1], dxr = a.Dxx[p + 2];
+				const double2 dym = ld2(a.Dyy + p - g.px), dyp = ld2(a.Dyy + p + g.px);
+				dzp[e] = ld2(a.Dzz + plane(z + 1) + off[e]);
+				s0.dxx = dxx.x; s1.dxx = dxx.y; s0.dyy = dyy.x; s1.dyy = dyy.y;
+				s0.dzz = dzc[e].x; s1.dzz = dzc[e].y;
+				s0.dxx_m = dxl;   s0.dxx_p = dxx.y;
+				s1.dxx_m = dxx.x; s1.dxx_p = dxr;
+				s0.dyy_m = dym.x; s1.dyy_m = dym.y; s0.dyy_p = dyp.x; s1.dyy_p = dyp.y;
+				s0.dzz_m = dzm[e].x; s1.dzz_m = dzm[e].y; s0.dzz_p = dzp[e].x; s1.dzz_p = dzp[e].y;
+				if (OFFD) {
+					const double2 dxy = ld2(a.Dxy + p);
+					const double xyl = a.Dxy[p - 1], xyr = a.Dxy[p + 2];
+					const double2 xym = ld2(a.Dxy + p - g.px), xyp = ld2(a.Dxy + p + g.px);
+					s0.dxy = dxy.x; s1.dxy = dxy.y;
+					s0.dxy_xm = xyl;   s0.dxy_xp = dxy.y;
+					s1.dxy_xm = dxy.x; s1.dxy_xp = xyr;
+					s0.dxy_ym = xym.x; s1.dxy_ym = xym.y; s0.dxy_yp = xyp.x; s1.dxy_yp = xyp.y;
+					// corner psi values from the LDS ring
+					const double ml = buf[li - LW - 1], mr = buf[li - LW + 2];
+					const double pl = buf[li + LW - 1], pr = buf[li + LW + 2];
+					s0.pmm = ml;   s0.ppm = ym.y; s0.pmp = pl;   s0.ppp = yp.y;
+					s1.pmm = ym.x; s1.ppm = mr;   s1.pmp = yp.x; s1.ppp = pr;
+				}
+			}
+			double2 out;
+			out.x = apply_op<VAR, OFFD, EXACT>(s0, a.op);
+			out.y = apply_op<VAR, OFFD, EXACT>(s1, a.op);
+			if (KIND == KF_RES) {
+				// residual = rhs - A*phi (Krylov.C:259, 325)
+				const double2 rh = ld2(a.RHS + p);
+				out.x = rh.x - out.x;
+				out.y = rh.y - out.y;
+			}
+			double2 comp = {0., 0.};
+			extras(z, e, comp);
+			const bool m0 = mrow[e] && mxx, m1 = mrow[e] && mxy;
+			if (m0 && m1) {
+				st2(a.O + p, out);
+				if (KIND == KF_RES) st2(a.O2 + p, out);
+			} else if (m0) {
+				a.O[p] = out.x;
+				if (KIND == KF_RES) a.O2[p] = out.x;
+			} else if (m1) {
+				a.O[p + 1] = out.y;
+				if (KIND == KF_RES) a.O2[p + 1] = out.y;
+			}
+			// dot products over counted interior points
+			const double w0 = (m0 && cnt) ? 1. : 0., w1 = (m1 && cnt) ? 1. : 0.;
+			if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
+				const double2 rt = ld2(a.RT + p);
+				acc[0] += w0 * (out.x * rt.x);
+				acc[0] += w1 * (out.y * rt.y);
+			} else if (KIND == KF_B0L) {
+				acc[0] += w0 * (pc[e].x * out.x);
+				acc[0] += w1 * (pc[e].y * out.y);
+				acc[1] += w0 * (out.x * out.x);
+				acc[1] += w1 * (out.y * out.y);
+			} else if (KIND == KF_B1L) {
+				acc[0] += w0 * (pc[e].x * pc[e].x);
+				acc[0] += w1 * (pc[e].y * pc[e].y);
+				acc[1] += w0 * (comp.x * pc[e].x);
+				acc[1] += w1 * (comp.y * pc[e].y);
+				acc[2] += w0 * (out.x * pc[e].x);
+				acc[2] += w1 * (out.y * pc[e].y);
+			} else if (KIND == KF_RES) {
+				acc[0] += w0 * (out.x * out.x);
+				acc[0] += w1 * (out.y * out.y);
+			}
+		}
+		// 4. rotate the z pipeline
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			pm[e] = pc[e];
+			pc[e] = pp[e];
+			if (VAR) { dzm[e] = dzc[e]; dzc[e] = dzp[e]; }
+		}
+		__syncthreads();
+	}
+	if (z1 - 1 == a.zhi && g.has_hi && a.zhi == g.mz) {
+		if (KIND == KF_A1 || KIND == KF_B1L) {
+#pragma unroll
+			for (int e = 0; e < VD; ++e) { double2 d; extras(g.mz + 1, e, d); }
+		}
+	}
+
+	if (KIND != KF_SPMV) {
+		KryRed r = a.red;
+		reduce_and_finalize<ND>(acc, r);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// streaming kernels of the MR part (no stencil): one block per plane segment
+// ---------------------------------------------------------------------------
+
+// l = 2 modified Gram-Schmidt step: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
+// (solveLin_BICGStab.C:420-428, jj = 2)
+__global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
+{
+	KryState *S = a.S;
+	if (S->done) return;
+	const double ntau = -S->tau[1][2];
+	double acc[2] = {0., 0.};
+	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+		const int z = a.zfirst + pl;
+		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
+		const long pb = (long)(z + 1) * a.g.ps;
+#pragma unroll
+		for (int i = 0; i < SEG2 / NT; ++i) {
+			const long q = 2 * ((long)blockIdx.x * SEG2 + i * NT + threadIdx.x);
+			if (q >= a.g.ps) break;
+			const long p = pb + q;
+			double2 r2 = ld2(a.v[2] + p), r1 = ld2(a.v[1] + p), r0 = ld2(a.v[0] + p);
+			r2 = axpy2(r2, r1, ntau);
+			st2(a.w[0] + p, r2);
+			if (cnt) {
+				acc[0] += r2.x * r2.x; acc[0] += r2.y * r2.y;
+				acc[1] += r0.x * r2.x; acc[1] += r0.y * r2.y;
+			}
+		}
+	}
+	reduce_and_finalize<2>(acc, a.red);
+}
+
+// End of an outer pass (solveLin_BICGStab.C:403, 450-464):
+//   phi += alpha*u0 (deferred from the last BiCG step); phi += gamma1*r0;
+//   r0 -= gammap_L*r_L; u0 -= gamma_L*u_L; then for jj = 1..L-1:
+//   u0 -= gamma_jj*u_jj; phi += gammapp_jj*r_jj; r0 -= gammap_jj*r_jj;
+//   dots |r0|^2 and (r0, r~).
+// v[0..L] = r0..rL, v[L+1..2L+1] = u0..uL, v[2L+2] = r~, w[0] = phi, w[1] = r0, w[2] = u0.
+template <int L>
+__global__ __launch_bounds__(NT) void k_final(const KryStream a)
+{
+	KryState *S = a.S;
+	if (S->done) return;
+	const double alpha = S->alpha;
+	double g1[L + 1], gp[L + 1], gpp[L + 1];
+#pragma unroll
+	for (int j = 1; j <= L; ++j) { g1[j] = S->gamma[j]; gp[j] = S->gammap[j]; gpp[j] = (j < L) ? S->gammapp[j] : 0.; }
+	double acc[2] = {0., 0.};
+	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+		const int z = a.zfirst + pl;
+		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
+		const long pb = (long)(z + 1) * a.g.ps;
+#pragma unroll
+		for (int i = 0; i < SEG2 / NT; ++i) {
+			const long q = 2 * ((long)blockIdx.x * SEG2 + i * NT + threadIdx.x);
+			if (q >= a.g.ps) break;
+			const long p = pb + q;
+			double2 r[L + 1], u[L + 1];
+#pragma unroll
+			for (int j = 0; j <= L; ++j) { r[j] = ld2(a.v[j] + p); u[j] = ld2(a.v[L + 1 + j] + p); }
+			double2 ph = ld2(a.w[0] + p);
+			const double2 rt = ld2(a.v[2 * L + 2] + p);
+			ph = axpy2(ph, u[0], alpha);
+			ph = axpy2(ph, r[0], g1[1]);
+			r[0] = axpy2(r[0], r[L], -gp[L]);
+			u[0] = axpy2(u[0], u[L], -g1[L]);
+#pragma unroll
+			for (int j = 1; j < L; ++j) {
+				u[0] = axpy2(u[0], u[j], -g1[j]);
+				ph = axpy2(ph, r[j], gpp[j]);
+				r[0] = axpy2(r[0], r[j], -gp[j]);
+			}
+			st2(a.w[0] + p, ph);
+			st2(a.w[1] + p, r[0]);
+			st2(a.w[2] + p, u[0]);
+			if (cnt) {
+				acc[0] += r[0].x * r[0].x; acc[0] += r[0].y * r[0].y;
+				acc[1] += r[0].x * rt.x;   acc[1] += r[0].y * rt.y;
+			}
+		}
+	}
+	reduce_and_finalize<2>(acc, a.red);
+}
+
+// ---------------------------------------------------------------------------
+// generic kernels: one per primitive, any face type
+// ---------------------------------------------------------------------------
+
+// dst = a + b*c over the whole stored box (NumMatrix whole-array operators)
+__global__ __launch_bounds__(NT) void g_axpy(double *dst, const double *x, const double *y, double c, long n2)
+{
+	for (long q = (long)blockIdx.x * NT + threadIdx.x; q < n2; q += (long)NT * gridDim.x)
+		st2(dst + 2 * q, axpy2(ld2(x + 2 * q), ld2(y + 2 * q), c));
+}
+
+// dst = a - b (Krylov.C:259)
+__global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const double *y, long n2)
+{
+	for (long q = (long)blockIdx.x * NT + threadIdx.x; q < n2; q += (long)NT * gridDim.x) {
+		double2 a = ld2(x + 2 * q), b = ld2(y + 2 * q), r;
+		r.x = a.x - b.x;
+		r.y = a.y - b.y;
+		st2(dst + 2 * q, r);
+	}
+}
+
+// BoundaryHandler3D::do_BCs, rim = 1 (BoundaryHandler.C:416-568); one launch per direction.
+// dir 0: a thread per (j,k) in [-1..my+1] x [-1..mz+1]
+// dir 1: a thread per (i,k) in [0..mx] x [-1..mz+1]
+// dir 2: a thread per (i,j) in [0..mx] x [0..my]; only on faces of the global domain
+__global__ void g_bc(double *d, KryGeo g, int dir)
+{
+	const int a = blockIdx.x * blockDim.x + threadIdx.x;
+	const int b = blockIdx.y;
+	if (dir == 0) {
+		const int j = a - 1, k = b - 1;
+		if (j > g.my + 1) return;
+		double *row = d + kry_idx(g, 0, j, k);   // row[i] = value at grid index i
+		if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
+		else if (g.bc[0] == 1) row[-1] = 2. * row[0] - row[1];
+		const int m = g.mx;
+		if (g.bc[1] == 0) { row[m] = 0.; row[m + 1] = 0.; }
+		else if (g.bc[1] == 1) {
+			row[m] = 2. * row[m - 1] - row[m - 2];
+			row[m + 1] = 2. * row[m] - row[m - 1];
+		}
+	} else if (dir == 1) {
+		const int i = a, k = b - 1;
+		if (i > g.mx) return;
+		double *c = d + kry_idx(g, i, 0, k);     // c[j*px]
+		const long s = g.px;
+		if (g.bc[2] == 0) { c[-s] = 0.; c[0] = 0.; }
+		else if (g.bc[2] == 1) c[-s] = 2. * c[0] - c[s];
+		const int m = g.my;
+		if (g.bc[3] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
+		else if (g.bc[3] == 1) {
+			c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
+			c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
+		}
+	} else {
+		const int i = a, j = b;
+		if (i > g.mx) return;
+		double *c = d + kry_idx(g, i, j, 0);
+		const long s = g.ps;
+		if (!g.has_lo) {
+			if (g.bc[4] == 0) { c[-s] = 0.; c[0] = 0.; }
+			else if (g.bc[4] == 1) {
+				c[-s] = 2. * c[0] - c[s];        // ghost first, from the OLD plane 0
+				c[0] = 2. * c[s] - c[2 * s];
+			}
+		}
+		const int m = g.mz;
+		if (!g.has_hi) {
+			if (g.bc[5] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
+			else if (g.bc[5] == 1) {
+				c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
+				c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
+			}
+		}
+	}
+}
+
+// Krylov::multiply_withMat on every point 0..m of the slab, neighbours read
+// from memory (ghosts included).  Grid: x over i, y over j, z over k.
+template <bool VAR, bool OFFD, bool EXACT>
+__global__ __launch_bounds__(NT) void g_spmv(KryGeo g, KryOp op, const double *psi, const double *lam,
+                                             const double *Dxx, const double *Dyy, const double *Dzz,
+                                             const double *Dxy, double *out)
+{
+	const int i = blockIdx.x * NT + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+	if (i > g.mx) return;
+	const long p = kry_idx(g, i, j, k), sx = g.px, sz = g.ps;
+	Sten s;
+	s.pc = psi[p]; s.xm = psi[p - 1]; s.xp = psi[p + 1];
+	s.ym = psi[p - sx]; s.yp = psi[p + sx]; s.zm = psi[p - sz]; s.zp = psi[p + sz];
+	s.lam = lam[p];
+	if (VAR) {
+		s.dxx = Dxx[p]; s.dyy = Dyy[p]; s.dzz = Dzz[p];
+		s.dxx_m = Dxx[p - 1]; s.dxx_p = Dxx[p + 1];
+		s.dyy_m = Dyy[p - sx]; s.dyy_p = Dyy[p + sx];
+		s.dzz_m = Dzz[p - sz]; s.dzz_p = Dzz[p + sz];
+		if (OFFD) {
+			s.dxy = Dxy[p];
+			s.dxy_xm = Dxy[p - 1]; s.dxy_xp = Dxy[p + 1];
+			s.dxy_ym = Dxy[p - sx]; s.dxy_yp = Dxy[p + sx];
+			s.pmm = psi[p - 1 - sx]; s.pmp = psi[p - 1 + sx];
+			s.ppm = psi[p + 1 - sx]; s.ppp = psi[p + 1 + sx];
+		}
+	}
+	out[p] = apply_op<VAR, OFFD, EXACT>(s, op);
+}
+
+// Weighted dot product / squared norm over points 0..m (Krylov.C:161-244, 36-157):
+// faces 1/2, edges 1/4, corners 1/8 (dot) or 1/4 (norm).  Slab interfaces are
+// counted once, by the lower slab.
+__global__ __launch_bounds__(NT) void g_wdot(KryGeo g, const double *x, const double *y, int norm_mode,
+                                             KryRed red)
+{
+	const int i = blockIdx.x * NT + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+	double acc[1] = {0.};
+	if (i <= g.mx) {
+		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
+		const bool bz = (k == 0 && !g.has_lo) || (k == g.mz && !g.has_hi);
+		double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
+		if (norm_mode && bx && by && bz) wgt = 0.25;
+		if (k == 0 && g.has_lo) wgt = 0.;
+		const long p = kry_idx(g, i, j, k);
+		acc[0] = wgt * (x[p] * y[p]);
+	}
+	reduce_and_finalize<1>(acc, red);
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+template <int KIND, int TY>
+static hipError_t launch_fused_t(const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
+{
+	dim3 grid(a.nblk), block(NT);
+#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, TY, V, O, E>), grid, block, 0, st, a)
+	if (!var) KRY_LAUNCH(false, false, true);
+	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
+	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
+#undef KRY_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
+{
+#define KRY_KIND(K)                                                              \
+	case K:                                                                      \
+		return ty == 8 ? launch_fused_t<K, 8>(a, var, offd, exact, st)           \
+		               : launch_fused_t<K, 16>(a, var, offd, exact, st);
+	switch (kind) {
+		KRY_KIND(KF_A0)
+		KRY_KIND(KF_A1)
+		KRY_KIND(KF_B0)
+		KRY_KIND(KF_B0L)
+		KRY_KIND(KF_B1L)
+		KRY_KIND(KF_RES)
+		KRY_KIND(KF_SPMV)
+	}
+#undef KRY_KIND
+	return hipErrorInvalidValue;
+}
+
+hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_mgs2, dim3(nbx, nby), dim3(NT), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st)
+{
+	if (L == 1) hipLaunchKernelGGL(k_final<1>, dim3(nbx, nby), dim3(NT), 0, st, a);
+	else if (L == 2) hipLaunchKernelGGL(k_final<2>, dim3(nbx, nby), dim3(NT), 0, st, a);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, st, S, phase);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_sum_slabs, dim3(1), dim3(64), 0, st, gather, nslabs, out);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st)
+{
+	const long n2 = n / 2;
+	hipLaunchKernelGGL(g_axpy, dim3(min(cdiv(n2, NT), 8192)), dim3(NT), 0, st, dst, x, y, c, n2);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st)
+{
+	const long n2 = n / 2;
+	hipLaunchKernelGGL(g_sub, dim3(min(cdiv(n2, NT), 8192)), dim3(NT), 0, st, dst, x, y, n2);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st)
+{
+	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.my + 3, 64), g.mz + 3), dim3(64), 0, st, d, g, 0);
+	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.mz + 3), dim3(64), 0, st, d, g, 1);
+	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,
+                            const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
+                            const double *Dxy, double *out, hipStream_t st)
+{
+	dim3 grid(cdiv(g.mx + 1, NT), g.my + 1, g.mz + 1), block(NT);
+	const bool ex = op.exact_rcp;
+#define KRY_G(V, O, E) hipLaunchKernelGGL((g_spmv<V, O, E>), grid, block, 0, st, g, op, psi, lam, Dxx, Dyy, Dzz, Dxy, out)
+	if (!var) KRY_G(false, false, true);
+	else if (!offd) { if (ex) KRY_G(true, false, true); else KRY_G(true, false, false); }
+	else { if (ex) KRY_G(true, true, true); else KRY_G(true, true, false); }
+#undef KRY_G
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_wdot(const KryGeo &g, const double *x, const double *y, int norm_mode, KryRed red,
+                           hipStream_t st)
+{
+	dim3 grid(cdiv(g.mx + 1, NT), g.my + 1, g.mz + 1), block(NT);
+	red.nblk = (int)(grid.x * grid.y * grid.z);
+	hipLaunchKernelGGL(g_wdot, grid, block, 0, st, g, x, y, norm_mode, red);
+	return hipGetLastError();
+}

@@ -1,0 +1,1305 @@
+// Host side of the MI355X BiCGStab(l) stencil solver and its C ABI.
+//
+// One kry_solver owns `slab_count` z slabs (one HIP device and stream each).
+// Slabs of other processes are reached through RCCL (kry_comm.cpp).  The outer
+// iteration is a fixed sequence of kernel launches; all recurrences' scalars
+// live on the device (KryState), so a pass needs no host round trip, and a
+// device-side `done` flag turns launches queued past convergence into no-ops.
+#include "../../include/krylov_amd.h"
+#include "kry_comm.h"
+#include "kry_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static void set_err(const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+}
+
+#define HIPCHK(expr)                                                                      \
+	do {                                                                                  \
+		hipError_t e_ = (expr);                                                           \
+		if (e_ != hipSuccess) {                                                           \
+			set_err("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+			return KRY_ERR_HIP;                                                           \
+		}                                                                                 \
+	} while (0)
+
+#define CHK(expr)                \
+	do {                         \
+		int s_ = (expr);         \
+		if (s_ < 0) return s_;   \
+	} while (0)
+
+namespace {
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct Field {
+	double *alloc = nullptr;
+	double *p = nullptr;       // (c=0, j=-1, k=-1)
+};
+
+enum { NPINGPONG = 2 };
+
+struct Slab {
+	int index = 0;             // global slab index
+	int device = 0;
+	hipStream_t st = nullptr;
+	hipEvent_t ev = nullptr;   // "this slab's last kernel of the phase is queued"
+	hipEvent_t ev_in = nullptr;
+	KryGeo g;
+	long guard = 0;
+	Field phi, rhs, lam, Dxx, Dyy, Dzz, Dxy, rt, tmp;
+	Field rb[KRY_LMAX + 1][NPINGPONG], ub[KRY_LMAX + 1][NPINGPONG];
+	KryState *S = nullptr;
+	KryState *Sh = nullptr;    // pinned host mirror (head of the struct only)
+	double *partial = nullptr;
+	long partial_cap = 0;
+	unsigned *counter = nullptr;
+	double *gather = nullptr;  // slab_count * KRY_NSUMS doubles (used on the first slab)
+	std::vector<Field *> all;
+};
+
+struct Prof {
+	std::vector<hipEvent_t> ev;
+	std::vector<int> kind;
+	size_t used = 0;
+};
+
+} // namespace
+
+struct kry_solver {
+	kry_desc d;
+	int L = 1;
+	int mzl = 0;               // slab-local mz
+	bool fused = false;        // fused Dirichlet path in use
+	bool var = false, offd = false;
+	bool loaded = false;
+	KryOp op;
+	int ty = 8, zc = 16;
+	int stream_blocks = 2048;  // target grid size of the streaming kernels
+	std::vector<Slab> slabs;
+	KryComm comm;
+	// run state
+	int it_base = 0;           // outer iterations completed (mirrors S->iter)
+	int status = 0;
+	bool done = false;
+	double norm_rhs = 0, norm_init = 0, norm_final = 0;
+	double solve_ms = 0, stage_ms = 0;
+	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
+	bool profile = false;
+	Prof prof;
+	double kernel_ms[8] = {0};
+	int kernel_calls[8] = {0};
+	int debug = 0;
+	// generic path scalars
+	double g_rho0 = 1, g_alpha = 0, g_omega = 1;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ memory
+
+int alloc_field(Slab &s, Field &f)
+{
+	HIPCHK(hipSetDevice(s.device));
+	const size_t total = (size_t)(s.g.n + 2 * s.guard + 32);
+	HIPCHK(hipMalloc((void **)&f.alloc, total * sizeof(double)));
+	HIPCHK(hipMemsetAsync(f.alloc, 0, total * sizeof(double), s.st));
+	// shift by 14 doubles: column 2 (grid index 0) then sits on a 128-byte boundary
+	f.p = f.alloc + s.guard + 14;
+	s.all.push_back(&f);
+	return 0;
+}
+
+void free_fields(Slab &s)
+{
+	hipSetDevice(s.device);
+	for (Field *f : s.all) {
+		if (f->alloc) hipFree(f->alloc);
+		f->alloc = f->p = nullptr;
+	}
+	s.all.clear();
+}
+
+// host box <-> device box.  Host planes of the slab start at k_host = index_local*mzl.
+int upload(kry_solver *h, Slab &s, int local_idx, Field &f, const double *host)
+{
+	HIPCHK(hipSetDevice(s.device));
+	const int mxh = h->d.mx[0], myh = h->d.mx[1];
+	const size_t hrow = (size_t)(mxh + 3);
+	const double *src = host + (size_t)local_idx * h->mzl * hrow * (myh + 3);
+	const size_t rows = (size_t)(myh + 3) * (s.g.mz + 3);
+	HIPCHK(hipMemcpy2DAsync(f.p + 1, (size_t)s.g.px * sizeof(double), src, hrow * sizeof(double),
+	                        hrow * sizeof(double), rows, hipMemcpyHostToDevice, s.st));
+	return 0;
+}
+
+int download(kry_solver *h, Slab &s, int local_idx, const Field &f, double *host)
+{
+	HIPCHK(hipSetDevice(s.device));
+	const int mxh = h->d.mx[0], myh = h->d.mx[1];
+	const size_t hrow = (size_t)(mxh + 3);
+	const size_t hplane = hrow * (myh + 3);
+	// owned planes: 0..mz, plus ghost -1 on the first local slab and mz+1 on the last
+	int k0 = (local_idx == 0) ? -1 : 0;
+	int k1 = (local_idx == (int)h->slabs.size() - 1) ? s.g.mz + 1 : s.g.mz;
+	double *dst = host + ((size_t)local_idx * h->mzl + (k0 + 1)) * hplane;
+	const double *src = f.p + 1 + (long)(k0 + 1) * s.g.ps;
+	const size_t rows = (size_t)(myh + 3) * (k1 - k0 + 1);
+	HIPCHK(hipMemcpy2DAsync(dst, hrow * sizeof(double), src, (size_t)s.g.px * sizeof(double),
+	                        hrow * sizeof(double), rows, hipMemcpyDeviceToHost, s.st));
+	return 0;
+}
+
+int sync_all(kry_solver *h)
+{
+	for (Slab &s : h->slabs) {
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipStreamSynchronize(s.st));
+	}
+	return 0;
+}
+
+// --------------------------------------------------------------- profiling
+
+void prof_begin(kry_solver *h, Slab &s, int kind)
+{
+	if (!h->profile || s.index != h->slabs[0].index) return;
+	Prof &p = h->prof;
+	if (p.used + 2 > p.ev.size()) {
+		for (int i = 0; i < 2; ++i) {
+			hipEvent_t e;
+			hipEventCreate(&e);
+			p.ev.push_back(e);
+		}
+	}
+	hipEventRecord(p.ev[p.used], s.st);
+	p.kind.resize(p.ev.size() / 2);
+	p.kind[p.used / 2] = kind;
+}
+
+void prof_end(kry_solver *h, Slab &s)
+{
+	if (!h->profile || s.index != h->slabs[0].index) return;
+	Prof &p = h->prof;
+	hipEventRecord(p.ev[p.used + 1], s.st);
+	p.used += 2;
+}
+
+void prof_collect(kry_solver *h)
+{
+	Prof &p = h->prof;
+	for (size_t i = 0; i + 1 < p.used; i += 2) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+			int k = p.kind[i / 2];
+			h->kernel_ms[k] += ms;
+			h->kernel_calls[k] += 1;
+		}
+	}
+	p.used = 0;
+}
+
+// ----------------------------------------------------- cross-slab plumbing
+
+// Make the values of S->sums identical on every slab of every process: the sum
+// over all slabs, added in slab order.  No-op for a single slab (the kernel's
+// last block already advanced the recurrences).
+int reduce_sums(kry_solver *h, int phase)
+{
+	const int ns = (int)h->slabs.size();
+	const bool remote = h->comm.active();
+	if (ns == 1 && !remote) return 0;
+	Slab &s0 = h->slabs[0];
+	double *tot = s0.S->sums;
+	if (ns > 1) {
+		for (int i = 0; i < ns; ++i) {
+			Slab &s = h->slabs[i];
+			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(hipMemcpyAsync(s0.gather + i * KRY_NSUMS, s.S->sums, KRY_NSUMS * sizeof(double),
+			                      hipMemcpyDeviceToDevice, s.st));
+			HIPCHK(hipEventRecord(s.ev, s.st));
+		}
+		HIPCHK(hipSetDevice(s0.device));
+		for (int i = 1; i < ns; ++i) HIPCHK(hipStreamWaitEvent(s0.st, h->slabs[i].ev, 0));
+		HIPCHK(kry_launch_sum_slabs(s0.gather, ns, tot, s0.st));
+	}
+	if (remote) CHK(h->comm.allreduce_sum(tot, KRY_NSUMS, s0.st));
+	if (ns > 1) {
+		HIPCHK(hipEventRecord(s0.ev_in, s0.st));
+		for (int i = 1; i < ns; ++i) {
+			Slab &s = h->slabs[i];
+			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(hipStreamWaitEvent(s.st, s0.ev_in, 0));
+			HIPCHK(hipMemcpyAsync(s.S->sums, tot, KRY_NSUMS * sizeof(double), hipMemcpyDeviceToDevice, s.st));
+		}
+	}
+	if (phase != PH_NONE) {
+		for (Slab &s : h->slabs) {
+			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(kry_launch_scalar(s.S, phase, s.st));
+		}
+	}
+	return 0;
+}
+
+// Fill the neighbour-owned ghost planes of a stencil output: plane 1 goes to the
+// lower neighbour's ghost mz+1, plane mz-1 to the upper neighbour's ghost -1
+// (BoundaryHandler.C:615-618, 761-765 for direction 2).
+int exchange_halo(kry_solver *h, std::vector<double *> &f)
+{
+	const int ns = (int)h->slabs.size();
+	if (ns == 1 && !h->comm.active()) return 0;
+	const size_t bytes = (size_t)h->slabs[0].g.ps * sizeof(double);
+	for (int i = 0; i < ns; ++i) {
+		HIPCHK(hipSetDevice(h->slabs[i].device));
+		HIPCHK(hipEventRecord(h->slabs[i].ev, h->slabs[i].st));
+	}
+	for (int i = 0; i + 1 < ns; ++i) {
+		Slab &lo = h->slabs[i], &hi = h->slabs[i + 1];
+		const KryGeo &g = lo.g;
+		// lo plane mz-1 -> hi ghost -1 ; hi plane 1 -> lo ghost mz+1
+		HIPCHK(hipSetDevice(hi.device));
+		HIPCHK(hipStreamWaitEvent(hi.st, lo.ev, 0));
+		HIPCHK(hipMemcpyAsync(f[i + 1] + 0 * g.ps, f[i] + (long)(g.mz - 1 + 1) * g.ps, bytes,
+		                      hipMemcpyDeviceToDevice, hi.st));
+		HIPCHK(hipSetDevice(lo.device));
+		HIPCHK(hipStreamWaitEvent(lo.st, hi.ev, 0));
+		HIPCHK(hipMemcpyAsync(f[i] + (long)(g.mz + 1 + 1) * g.ps, f[i + 1] + (long)(1 + 1) * g.ps, bytes,
+		                      hipMemcpyDeviceToDevice, lo.st));
+	}
+	if (h->comm.active()) {
+		// with RCCL a process owns exactly one slab (checked in kry_comm_init)
+		Slab &s = h->slabs[0];
+		const KryGeo &g = s.g;
+		double *b = f[0];
+		HIPCHK(hipSetDevice(s.device));
+		CHK(h->comm.halo(g.has_lo ? s.index - 1 : -1, b + 2L * g.ps, b,
+		                 g.has_hi ? s.index + 1 : -1, b + (long)g.mz * g.ps, b + (long)(g.mz + 2) * g.ps,
+		                 (size_t)g.ps, s.st));
+	}
+	return 0;
+}
+
+// A halo exchange orders the streams of neighbouring local slabs; after a
+// pointwise-only kernel nothing needs to move, so nothing is exchanged.
+
+KryRed make_red(Slab &s, int nblk, int phase)
+{
+	KryRed r;
+	r.partial = s.partial;
+	r.counter = s.counter;
+	r.S = s.S;
+	r.nblk = nblk;
+	r.phase = phase;
+	return r;
+}
+
+// ------------------------------------------------------------ fused path
+
+struct Tiling {
+	int ntx, nty, nchunk, nblk, zlo, zhi;
+};
+
+Tiling tiling(const kry_solver *h, const Slab &s)
+{
+	Tiling t;
+	t.ntx = (s.g.mx + KRY_TXW - 1) / KRY_TXW;       // columns i = 0 .. mx-1
+	t.nty = (s.g.my + h->ty - 1) / h->ty;             // rows    j = 0 .. my-1
+	t.zlo = s.g.has_lo ? 0 : 1;
+	t.zhi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
+	const int nz = t.zhi - t.zlo + 1;
+	t.nchunk = (nz + h->zc - 1) / h->zc;
+	t.nblk = t.ntx * t.nty * t.nchunk;
+	return t;
+}
+
+KryFused fused_base(kry_solver *h, Slab &s, int phase)
+{
+	KryFused a;
+	memset(&a, 0, sizeof a);
+	Tiling t = tiling(h, s);
+	a.g = s.g;
+	a.op = h->op;
+	a.S = s.S;
+	a.lam = s.lam.p;
+	a.Dxx = s.Dxx.p; a.Dyy = s.Dyy.p; a.Dzz = s.Dzz.p; a.Dxy = s.Dxy.p;
+	a.RT = s.rt.p;
+	a.RHS = s.rhs.p;
+	a.phi = s.phi.p;
+	a.zlo = t.zlo; a.zhi = t.zhi; a.zc = h->zc;
+	a.ntx = t.ntx; a.nty = t.nty; a.nchunk = t.nchunk; a.nblk = t.nblk;
+	a.red = make_red(s, t.nblk, phase);
+	return a;
+}
+
+int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a)
+{
+	HIPCHK(hipSetDevice(s.device));
+	prof_begin(h, s, kind);
+	HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
+	prof_end(h, s);
+	return 0;
+}
+
+KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby)
+{
+	KryStream a;
+	memset(&a, 0, sizeof a);
+	a.g = s.g;
+	a.S = s.S;
+	// planes touched: every plane whose values this slab must keep current
+	const int zf = s.g.has_lo ? -1 : 1;
+	const int zl = s.g.has_hi ? s.g.mz + 1 : s.g.mz - 1;
+	a.zfirst = zf;
+	a.nplanes = zl - zf + 1;
+	a.cnt_lo = 1;
+	a.cnt_hi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
+	// about 2048 blocks: segments of a plane in x, groups of planes in y
+	*nbx = (int)((s.g.ps + KRY_SEG - 1) / KRY_SEG);
+	*nby = std::max(1, std::min(a.nplanes, (h->stream_blocks + *nbx - 1) / *nbx));
+	a.red = make_red(s, (*nbx) * (*nby), phase);
+	return a;
+}
+
+// one outer pass, solveLin_BICGStab.C:327-496, as fused kernels
+int fused_pass(kry_solver *h, int it)
+{
+	const int p = it & 1, q = 1 - p;
+	const int L = h->L;
+	std::vector<double *> outs(h->slabs.size());
+	auto for_slabs = [&](auto &&fn) -> int {
+		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
+		return 0;
+	};
+
+	// --- jj = 0, A: u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
+	CHK(for_slabs([&](Slab &s, int i) -> int {
+		KryFused a = fused_base(h, s, PH_A);
+		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
+		a.O = (L == 1 ? s.ub[1][0].p : s.ub[1][p].p);
+		outs[i] = a.O;
+		return launch_fused(h, s, KF_A0, a);
+	}));
+	CHK(exchange_halo(h, outs));
+	CHK(reduce_sums(h, PH_A));
+
+	if (L == 1) {
+		// --- B (last): r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
+		CHK(for_slabs([&](Slab &s, int i) -> int {
+			KryFused a = fused_base(h, s, PH_BL1);
+			a.X = s.rb[0][p].p; a.Y = s.ub[1][0].p; a.Xout = s.rb[0][q].p;
+			a.O = s.rb[1][0].p;
+			outs[i] = a.O;
+			return launch_fused(h, s, KF_B0L, a);
+		}));
+		CHK(exchange_halo(h, outs));
+		CHK(reduce_sums(h, PH_BL1));
+	} else {
+		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
+		CHK(for_slabs([&](Slab &s, int i) -> int {
+			KryFused a = fused_base(h, s, PH_B);
+			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
+			a.O = s.rb[1][p].p;
+			outs[i] = a.O;
+			return launch_fused(h, s, KF_B0, a);
+		}));
+		CHK(exchange_halo(h, outs));
+		CHK(reduce_sums(h, PH_B));
+		// --- jj = 1, A: phi += alpha*u0 ; u0 = r0 - beta*u0 ; u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
+		CHK(for_slabs([&](Slab &s, int i) -> int {
+			KryFused a = fused_base(h, s, PH_A);
+			a.X = s.rb[1][p].p; a.Y = s.ub[1][p].p; a.Xout = s.ub[1][q].p;
+			a.O = s.ub[2][0].p;
+			a.E = s.ub[0][q].p; a.Ea = s.rb[0][q].p;
+			outs[i] = a.O;
+			return launch_fused(h, s, KF_A1, a);
+		}));
+		CHK(exchange_halo(h, outs));
+		CHK(reduce_sums(h, PH_A));
+		// --- jj = 1, B (last): r0 -= alpha*u1 ; r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0,r1), (r2,r1)
+		CHK(for_slabs([&](Slab &s, int i) -> int {
+			KryFused a = fused_base(h, s, PH_BL2);
+			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
+			a.O = s.rb[2][0].p;
+			a.E = s.rb[0][q].p; a.Ea = s.ub[1][q].p;
+			outs[i] = a.O;
+			return launch_fused(h, s, KF_B1L, a);
+		}));
+		CHK(exchange_halo(h, outs));
+		CHK(reduce_sums(h, PH_BL2));
+		// --- MR: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
+		CHK(for_slabs([&](Slab &s, int) -> int {
+			int nbx, nby;
+			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby);
+			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
+			a.w[0] = s.rb[2][0].p;
+			HIPCHK(hipSetDevice(s.device));
+			prof_begin(h, s, 6);
+			HIPCHK(kry_launch_mgs2(a, nbx, nby, s.st));
+			prof_end(h, s);
+			return 0;
+		}));
+		CHK(reduce_sums(h, PH_M2));
+	}
+
+	// --- end of pass: phi, r0, u0 updates ; |r0|^2, (r0, r~)
+	CHK(for_slabs([&](Slab &s, int) -> int {
+		int nbx, nby;
+		KryStream a = stream_base(h, s, PH_F, &nbx, &nby);
+		if (L == 1) {
+			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][0].p;
+			a.v[2] = s.ub[0][q].p; a.v[3] = s.ub[1][0].p;
+			a.v[4] = s.rt.p;
+		} else {
+			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
+			a.v[3] = s.ub[0][q].p; a.v[4] = s.ub[1][q].p; a.v[5] = s.ub[2][0].p;
+			a.v[6] = s.rt.p;
+		}
+		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p; a.w[2] = s.ub[0][q].p;
+		HIPCHK(hipSetDevice(s.device));
+		prof_begin(h, s, 7);
+		HIPCHK(kry_launch_final(L, a, nbx, nby, s.st));
+		prof_end(h, s);
+		return 0;
+	}));
+	CHK(reduce_sums(h, PH_F));
+	return 0;
+}
+
+// fetch iter/done/status/norm of the first slab (identical on all)
+int poll_state(kry_solver *h)
+{
+	Slab &s = h->slabs[0];
+	HIPCHK(hipSetDevice(s.device));
+	HIPCHK(hipMemcpyAsync(s.Sh, s.S, offsetof(KryState, hist), hipMemcpyDeviceToHost, s.st));
+	HIPCHK(hipStreamSynchronize(s.st));
+	h->it_base = s.Sh->iter;
+	h->done = s.Sh->done != 0;
+	h->status = s.Sh->status;
+	h->norm_final = s.Sh->norm;
+	h->norm_init = s.Sh->norm_init;
+	return 0;
+}
+
+// ---------------------------------------------------------- generic path
+
+struct Gen {
+	kry_solver *h;
+	int ns() const { return (int)h->slabs.size(); }
+};
+
+int g_do_bcs(kry_solver *h, Field Slab::*f)
+{
+	for (Slab &s : h->slabs) {
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_bcs((s.*f).p, s.g, s.st));
+	}
+	return 0;
+}
+
+int g_do_bcs_p(kry_solver *h, std::vector<double *> &f)
+{
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_bcs(f[i], s.g, s.st));
+	}
+	return 0;
+}
+
+// weighted dot over all slabs -> host value
+int g_dot(kry_solver *h, std::vector<double *> &x, std::vector<double *> &y, int norm_mode, double *out)
+{
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_wdot(s.g, x[i], y[i], norm_mode, make_red(s, 0, PH_NONE), s.st));
+	}
+	CHK(reduce_sums(h, PH_NONE));
+	Slab &s0 = h->slabs[0];
+	HIPCHK(hipSetDevice(s0.device));
+	HIPCHK(hipMemcpyAsync(s0.Sh->sums, s0.S->sums, sizeof(double), hipMemcpyDeviceToHost, s0.st));
+	HIPCHK(hipStreamSynchronize(s0.st));
+	*out = s0.Sh->sums[0];
+	return 0;
+}
+
+std::vector<double *> ptrs(kry_solver *h, Field Slab::*f)
+{
+	std::vector<double *> v;
+	for (Slab &s : h->slabs) v.push_back((s.*f).p);
+	return v;
+}
+std::vector<double *> ptrs_r(kry_solver *h, int k)
+{
+	std::vector<double *> v;
+	for (Slab &s : h->slabs) v.push_back(s.rb[k][0].p);
+	return v;
+}
+std::vector<double *> ptrs_u(kry_solver *h, int k)
+{
+	std::vector<double *> v;
+	for (Slab &s : h->slabs) v.push_back(s.ub[k][0].p);
+	return v;
+}
+
+// dst = x + y*c on every slab (whole stored box)
+int g_axpy(kry_solver *h, std::vector<double *> &dst, std::vector<double *> &x, std::vector<double *> &y, double c)
+{
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_axpy(dst[i], x[i], y[i], c, s.g.n, s.st));
+	}
+	return 0;
+}
+
+// Krylov::multiply_withMat incl. its boundary handling (Krylov.C:500-541 / 407-496)
+int g_spmv(kry_solver *h, std::vector<double *> &psi, std::vector<double *> &out, bool apply_bcs)
+{
+	if (!h->var) CHK(g_do_bcs_p(h, psi));      // Krylov.C:516
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_gspmv(s.g, h->op, h->var, h->offd, psi[i], s.lam.p, s.Dxx.p, s.Dyy.p, s.Dzz.p,
+		                        s.Dxy.p, out[i], s.st));
+	}
+	if (apply_bcs) CHK(g_do_bcs_p(h, out));
+	CHK(exchange_halo(h, out));
+	return 0;
+}
+
+double g_norm_from(double sumsq) { return std::sqrt(sumsq); }
+
+bool host_really_is_nan(double xd)
+{
+	float x = (float)xd;
+	unsigned bits;
+	memcpy(&bits, &x, sizeof bits);
+	return (bits & 0x7F800000u) == 0x7F800000u;
+}
+
+// Krylov::get_Residual (Krylov.C:248-306, 311-402) into r[0]
+int g_residual(kry_solver *h)
+{
+	auto phi = ptrs(h, &Slab::phi), rhs = ptrs(h, &Slab::rhs), r0 = ptrs_r(h, 0);
+	CHK(g_spmv(h, phi, r0, false));
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_sub(r0[i], rhs[i], r0[i], s.g.n, s.st));
+	}
+	CHK(g_do_bcs_p(h, r0));
+	CHK(exchange_halo(h, r0));
+	return 0;
+}
+
+// one outer pass with host scalars, statement by statement as
+// solveLin_BICGStab.C:341-496
+int generic_pass(kry_solver *h, double *sigma, double *gammap, double *gamma, double *gammapp,
+                 double (*tau)[KRY_LMAX + 1])
+{
+	const int L = h->L;
+	auto rt = ptrs(h, &Slab::rt), phi = ptrs(h, &Slab::phi);
+	std::vector<std::vector<double *>> r(L + 1), u(L + 1);
+	for (int k = 0; k <= L; ++k) { r[k] = ptrs_r(h, k); u[k] = ptrs_u(h, k); }
+
+	h->g_rho0 *= -h->g_omega;
+	for (int jj = 0; jj < L; ++jj) {
+		double rho1;
+		CHK(g_dot(h, r[jj], rt, 0, &rho1));
+		double beta = h->g_alpha * rho1 / h->g_rho0;
+		h->g_rho0 = rho1;
+		for (int ii = 0; ii <= jj; ++ii) CHK(g_axpy(h, u[ii], r[ii], u[ii], -beta));
+		CHK(g_spmv(h, u[jj], u[jj + 1], true));
+		double d;
+		CHK(g_dot(h, u[jj + 1], rt, 0, &d));
+		h->g_alpha = h->g_rho0 / d;
+		for (int ii = 0; ii <= jj; ++ii) CHK(g_axpy(h, r[ii], r[ii], u[ii + 1], -h->g_alpha));
+		CHK(g_spmv(h, r[jj], r[jj + 1], true));
+		CHK(g_axpy(h, phi, phi, u[0], h->g_alpha));
+		if (host_really_is_nan(h->g_alpha)) {
+			if (h->debug > 0) printf(" alpha is nan %d %g %g %g\n", jj, h->g_rho0, rho1, beta);
+			h->status = KRY_NAN_ALPHA;
+			h->done = true;
+			return 0;
+		}
+	}
+	for (int jj = 1; jj <= L; ++jj) {
+		for (int ii = 1; ii < jj; ++ii) {
+			double d;
+			CHK(g_dot(h, r[jj], r[ii], 0, &d));
+			tau[ii][jj] = d / sigma[ii];
+			CHK(g_axpy(h, r[jj], r[jj], r[ii], -tau[ii][jj]));
+		}
+		CHK(g_dot(h, r[jj], r[jj], 0, &sigma[jj]));
+		double d;
+		CHK(g_dot(h, r[0], r[jj], 0, &d));
+		gammap[jj] = d / sigma[jj];
+	}
+	h->g_omega = gamma[L] = gammap[L];
+	for (int jj = L - 1; jj >= 1; --jj) {
+		gamma[jj] = gammap[jj];
+		for (int ii = jj + 1; ii <= L; ++ii) gamma[jj] -= tau[jj][ii] * gamma[ii];
+	}
+	for (int jj = 1; jj < L; ++jj) {
+		gammapp[jj] = gamma[jj + 1];
+		for (int ii = jj + 1; ii < L; ++ii) gammapp[jj] += tau[jj][ii] * gamma[ii + 1];
+	}
+	CHK(g_axpy(h, phi, phi, r[0], gamma[1]));
+	CHK(g_axpy(h, r[0], r[0], r[L], -gammap[L]));
+	CHK(g_axpy(h, u[0], u[0], u[L], -gamma[L]));
+	for (int jj = 1; jj < L; ++jj) {
+		CHK(g_axpy(h, u[0], u[0], u[jj], -gamma[jj]));
+		CHK(g_axpy(h, phi, phi, r[jj], gammapp[jj]));
+		CHK(g_axpy(h, r[0], r[0], r[jj], -gammap[jj]));
+	}
+	double ss;
+	CHK(g_dot(h, r[0], r[0], 1, &ss));
+	double norm = g_norm_from(ss);
+	h->norm_final = norm;
+	h->hist.push_back(norm);
+	h->it_base += 1;
+	if (host_really_is_nan(norm)) {
+		if (h->debug > 0) printf(" Norm is nan at iteration %d\n", h->it_base);
+		h->status = KRY_NAN_NORM;
+		h->done = true;
+		return 0;
+	}
+	if (!(norm > h->d.eps * h->norm_rhs)) { h->done = true; return 0; }
+	if (h->d.max_outer > 0 && h->it_base >= h->d.max_outer) { h->status = KRY_MAX_ITER; h->done = true; }
+	return 0;
+}
+
+// --------------------------------------------------------- setup helpers
+
+bool is_pow2(double v)
+{
+	int e;
+	return std::frexp(v, &e) == 0.5;
+}
+
+void make_op(kry_solver *h, bool var, const double Dc[3])
+{
+	KryOp &op = h->op;
+	const double *dx = h->d.delx;
+	for (int d = 0; d < 3; ++d) {
+		op.c[d] = var ? 1. / (dx[d] * dx[d]) : Dc[d] / (dx[d] * dx[d]);   // Krylov.C:424 / 513
+		op.two_d[d] = 2. * dx[d];
+		op.inv_two_d[d] = 1. / op.two_d[d];
+	}
+	op.cd2 = 2. * (op.c[0] + op.c[1] + op.c[2]);
+	op.cxy = 1. / (2. * dx[0] * dx[1]);
+	op.exact_rcp = (is_pow2(op.two_d[0]) && is_pow2(op.two_d[1]) && is_pow2(op.two_d[2])) ? 1 : 0;
+}
+
+int stage_common(kry_solver *h, const double *phi, const double *rhs, const double *lam,
+                 const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy)
+{
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		CHK(upload(h, s, (int)i, s.phi, phi));
+		CHK(upload(h, s, (int)i, s.rhs, rhs));
+		CHK(upload(h, s, (int)i, s.lam, lam));
+		if (h->var) {
+			CHK(upload(h, s, (int)i, s.Dxx, Dxx));
+			CHK(upload(h, s, (int)i, s.Dyy, Dyy));
+			CHK(upload(h, s, (int)i, s.Dzz, Dzz));
+			if (h->offd) CHK(upload(h, s, (int)i, s.Dxy, Dxy));
+		}
+	}
+	return 0;
+}
+
+// zero a field's interior + ghosts (keeps guard zones zero as well)
+int zero_field(Slab &s, Field &f)
+{
+	HIPCHK(hipSetDevice(s.device));
+	HIPCHK(hipMemsetAsync(f.p, 0, (size_t)s.g.n * sizeof(double), s.st));
+	return 0;
+}
+
+// prologue of solve_int (solveLin_BICGStab.C:268-320)
+int prologue(kry_solver *h)
+{
+	h->it_base = 0;
+	h->status = 0;
+	h->done = false;
+	h->hist.clear();
+	h->g_rho0 = 1.; h->g_alpha = 0.; h->g_omega = 1.;
+
+	// the reference allocates zeroed work vectors once (make_Arrays) and starts
+	// the recurrences with u = 0 via beta = 0; start from zeros on every load
+	for (Slab &s : h->slabs) {
+		for (int k = 0; k <= h->L; ++k)
+			for (int b = 0; b < NPINGPONG; ++b) {
+				if (s.rb[k][b].p) CHK(zero_field(s, s.rb[k][b]));
+				if (s.ub[k][b].p) CHK(zero_field(s, s.ub[k][b]));
+			}
+		CHK(zero_field(s, s.rt));
+	}
+
+	// normRHS = l2(rhs), zero -> one (:268-269)
+	auto rhs = ptrs(h, &Slab::rhs);
+	double ss;
+	CHK(g_dot(h, rhs, rhs, 1, &ss));
+	h->norm_rhs = std::sqrt(ss);
+	if (h->norm_rhs == 0.) h->norm_rhs = 1.;
+
+	if (h->fused) {
+		for (Slab &s : h->slabs) {
+			HIPCHK(hipSetDevice(s.device));
+			KryState init;
+			memset(&init, 0, offsetof(KryState, hist));
+			init.eps = h->d.eps;
+			init.norm_rhs = h->norm_rhs;
+			init.max_outer = h->d.max_outer;
+			init.L = h->L;
+			init.local_scalars = (h->slabs.size() == 1 && !h->comm.active()) ? 1 : 0;
+			memcpy(s.Sh, &init, offsetof(KryState, hist));
+			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
+			HIPCHK(hipStreamSynchronize(s.st));
+		}
+		// constant-coefficient operator: do_BCs on its input (Krylov.C:516)
+		if (!h->var) CHK(g_do_bcs(h, &Slab::phi));
+		std::vector<double *> outs(h->slabs.size()), outs2(h->slabs.size());
+		for (size_t i = 0; i < h->slabs.size(); ++i) {
+			Slab &s = h->slabs[i];
+			KryFused a = fused_base(h, s, PH_INIT);
+			a.X = s.phi.p;
+			a.O = s.rb[0][0].p;
+			a.O2 = s.rt.p;
+			outs[i] = a.O;
+			outs2[i] = a.O2;
+			CHK(launch_fused(h, s, KF_RES, a));
+		}
+		CHK(exchange_halo(h, outs));
+		CHK(exchange_halo(h, outs2));
+		CHK(reduce_sums(h, PH_INIT));
+		CHK(poll_state(h));
+	} else {
+		CHK(g_residual(h));
+		auto r0 = ptrs_r(h, 0), rt = ptrs(h, &Slab::rt);
+		CHK(g_dot(h, r0, r0, 1, &ss));
+		h->norm_init = std::sqrt(ss);
+		h->norm_final = 1.e99;
+		if (h->norm_init < h->d.eps * h->norm_rhs) {
+			h->done = true;
+			h->norm_final = h->norm_init;
+		} else {
+			for (size_t i = 0; i < h->slabs.size(); ++i) {
+				Slab &s = h->slabs[i];
+				HIPCHK(hipSetDevice(s.device));
+				HIPCHK(hipMemcpyAsync(rt[i], r0[i], (size_t)s.g.n * sizeof(double), hipMemcpyDeviceToDevice, s.st));
+			}
+		}
+	}
+	return 0;
+}
+
+int run_iterations(kry_solver *h, int n_outer)
+{
+	if (!h->loaded) { set_err("kry_iterate: no problem loaded"); return KRY_ERR_STATE; }
+	if (h->done) return h->status;
+	hipEvent_t e0, e1;
+	Slab &s0 = h->slabs[0];
+	HIPCHK(hipSetDevice(s0.device));
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	HIPCHK(hipEventRecord(e0, s0.st));
+	int left = n_outer;   // <= 0: until done
+	if (h->fused) {
+		// launch in batches; kernels past convergence are no-ops on the device
+		const int batch_max = (h->debug > 2) ? 1 : 8;
+		while (!h->done && (n_outer <= 0 || left > 0)) {
+			int nb = (n_outer <= 0) ? batch_max : std::min(batch_max, left);
+			const int it0 = h->it_base;
+			double t0 = now_ms();
+			for (int i = 0; i < nb; ++i) CHK(fused_pass(h, it0 + i));
+			CHK(poll_state(h));
+			if (h->debug > 2) {
+				Slab &s = h->slabs[0];
+				(void)s;
+				printf(" Iteration: %d (%.3f ms)\n", h->it_base, now_ms() - t0);
+				printf(" My error norm: %g %g %g %g %g \n", h->norm_final, std::sqrt(h->norm_final),
+				       h->d.eps * h->norm_rhs, h->d.eps, h->norm_rhs);
+			}
+			if (n_outer > 0) left -= nb;
+			if (!h->done && h->it_base != it0 + nb) {
+				set_err("device iteration counter %d != host %d", h->it_base, it0 + nb);
+				return KRY_ERR_STATE;
+			}
+		}
+	} else {
+		double sigma[KRY_LMAX + 1] = {0}, gammap[KRY_LMAX + 1] = {0}, gamma[KRY_LMAX + 1] = {0},
+		       gammapp[KRY_LMAX + 1] = {0};
+		static thread_local double tau[KRY_LMAX + 1][KRY_LMAX + 1];
+		while (!h->done && (n_outer <= 0 || left > 0)) {
+			double t0 = now_ms();
+			CHK(generic_pass(h, sigma, gammap, gamma, gammapp, tau));
+			if (h->debug > 2) {
+				printf(" Iteration: %d (%.3f ms)\n", h->it_base, now_ms() - t0);
+				printf(" My error norm: %g %g %g %g %g \n", h->norm_final, std::sqrt(h->norm_final),
+				       h->d.eps * h->norm_rhs, h->d.eps, h->norm_rhs);
+			}
+			if (n_outer > 0) left -= 1;
+		}
+	}
+	HIPCHK(hipSetDevice(s0.device));
+	HIPCHK(hipEventRecord(e1, s0.st));
+	CHK(sync_all(h));
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	h->solve_ms += ms;
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	if (h->profile) prof_collect(h);
+	return h->status;
+}
+
+int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const double *phi, const double *rhs,
+                const double *lam, const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy)
+{
+	if (!phi || !rhs || !lam || (var && (!Dxx || !Dyy || !Dzz)) || (var && offd && !Dxy)) {
+		set_err("null field pointer");
+		return KRY_ERR_ARG;
+	}
+	double t0 = now_ms();
+	h->var = var;
+	h->offd = var && offd;
+	make_op(h, var, Dc);
+	bool dirichlet = true;
+	for (int f = 0; f < 6; ++f) dirichlet = dirichlet && (h->d.bc_type[f] == 0);
+	h->fused = dirichlet && h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
+	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
+	if (h->slabs.size() > 1 || h->comm.active()) {
+		// interface ghosts of the inputs, as solve_int does under `parallel`
+		// (solveLin_BICGStab.C:259-263) and the operator does for its input (Krylov.C:516)
+		Field Slab::*fl[] = {&Slab::phi, &Slab::Dxx, &Slab::Dyy, &Slab::Dzz, &Slab::Dxy};
+		for (int k = 0; k < (h->var ? (h->offd ? 5 : 4) : 1); ++k) {
+			auto v = ptrs(h, fl[k]);
+			CHK(exchange_halo(h, v));
+		}
+	}
+	h->loaded = true;
+	h->solve_ms = 0;
+	CHK(prologue(h));
+	CHK(sync_all(h));
+	h->stage_ms = now_ms() - t0;
+	return h->status;
+}
+
+int finish_solve(kry_solver *h, double *phi)
+{
+	double t0 = now_ms();
+	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(download(h, h->slabs[i], (int)i, h->slabs[i].phi, phi));
+	CHK(sync_all(h));
+	h->stage_ms += now_ms() - t0;
+	return 0;
+}
+
+} // namespace
+
+// ===================================================================== C ABI
+
+extern "C" {
+
+const char *kry_last_error(void) { return g_err.c_str(); }
+
+const char *kry_status_string(int st)
+{
+	switch (st) {
+	case KRY_OK: return "ok";
+	case KRY_NAN_ALPHA: return "alpha is nan";
+	case KRY_NAN_NORM: return "norm is nan";
+	case KRY_MAX_ITER: return "iteration cap reached";
+	case KRY_ERR_ARG: return "invalid argument";
+	case KRY_ERR_HIP: return "HIP error";
+	case KRY_ERR_COMM: return "communication error";
+	case KRY_ERR_STATE: return "invalid state";
+	}
+	return "unknown";
+}
+
+kry_handle kry_create(const kry_desc *d, int *status)
+{
+	auto fail = [&](int st) -> kry_handle {
+		if (status) *status = st;
+		return nullptr;
+	};
+	if (!d) { set_err("null descriptor"); return fail(KRY_ERR_ARG); }
+	if (d->L < 1 || d->L > KRY_LMAX) { set_err("L=%d outside 1..%d", d->L, KRY_LMAX); return fail(KRY_ERR_ARG); }
+	if (d->nslabs < 1 || d->slab_count < 1 || d->slab_count > KRY_MAX_SLABS || d->slab_begin < 0 ||
+	    d->slab_begin + d->slab_count > d->nslabs) {
+		set_err("bad slab range: nslabs=%d begin=%d count=%d", d->nslabs, d->slab_begin, d->slab_count);
+		return fail(KRY_ERR_ARG);
+	}
+	for (int k = 0; k < 3; ++k)
+		if (d->mx[k] < 4 || !(d->delx[k] > 0.)) { set_err("bad grid: mx[%d]=%d delx=%g", k, d->mx[k], d->delx[k]); return fail(KRY_ERR_ARG); }
+	if (d->mx[2] % d->slab_count != 0 || d->mx[2] / d->slab_count < 4) {
+		set_err("mz=%d not divisible into %d slabs of >= 4 planes", d->mx[2], d->slab_count);
+		return fail(KRY_ERR_ARG);
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+		set_err("no HIP device available");
+		return fail(KRY_ERR_HIP);
+	}
+	for (int i = 0; i < d->slab_count; ++i)
+		if (d->devices[i] < 0 || d->devices[i] >= ndev) { set_err("device %d out of range (have %d)", d->devices[i], ndev); return fail(KRY_ERR_ARG); }
+
+	kry_solver *h = new kry_solver();
+	h->d = *d;
+	h->L = d->L;
+	h->mzl = d->mx[2] / d->slab_count;
+	if (const char *e = getenv("KRY_TY")) h->ty = (atoi(e) == 8) ? 8 : 16;
+	if (const char *e = getenv("KRY_ZC")) h->zc = std::max(1, atoi(e));
+	if (const char *e = getenv("KRY_STREAM_BLOCKS")) h->stream_blocks = std::max(64, atoi(e));
+	if (const char *e = getenv("KRY_PROFILE")) h->profile = atoi(e) != 0;
+	h->slabs.resize(d->slab_count);
+	int st = 0;
+	auto build = [&]() -> int {
+		for (int i = 0; i < d->slab_count; ++i) {
+			Slab &s = h->slabs[i];
+			s.index = d->slab_begin + i;
+			s.device = d->devices[i];
+			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+			HIPCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+			KryGeo &g = s.g;
+			g.mx = d->mx[0]; g.my = d->mx[1]; g.mz = h->mzl;
+			g.px = ((g.mx + 4 + 15) / 16) * 16;
+			g.ps = (long)g.px * (g.my + 3);
+			g.n = g.ps * (g.mz + 3);
+			g.has_lo = s.index > 0;
+			g.has_hi = s.index < d->nslabs - 1;
+			for (int f = 0; f < 6; ++f) g.bc[f] = d->bc_type[f];
+			s.guard = 20L * g.px + 256;
+			CHK(alloc_field(s, s.phi));
+			CHK(alloc_field(s, s.rhs));
+			CHK(alloc_field(s, s.lam));
+			CHK(alloc_field(s, s.Dxx));
+			CHK(alloc_field(s, s.Dyy));
+			CHK(alloc_field(s, s.Dzz));
+			CHK(alloc_field(s, s.Dxy));
+			CHK(alloc_field(s, s.rt));
+			for (int k = 0; k <= h->L; ++k) {
+				// vectors that feed a fused stencil after an update need a ping-pong partner
+				const int nb = (k < h->L && h->L <= 2) ? 2 : 1;
+				for (int b = 0; b < nb; ++b) {
+					CHK(alloc_field(s, s.rb[k][b]));
+					CHK(alloc_field(s, s.ub[k][b]));
+				}
+			}
+			HIPCHK(hipMalloc((void **)&s.S, sizeof(KryState)));
+			HIPCHK(hipMemsetAsync(s.S, 0, sizeof(KryState), s.st));
+			HIPCHK(hipHostMalloc((void **)&s.Sh, offsetof(KryState, hist), hipHostMallocDefault));
+			memset(s.Sh, 0, offsetof(KryState, hist));
+			// partial sums: the generic dot uses one block per grid row
+			s.partial_cap = (long)KRY_NSUMS * std::max<long>((long)(g.my + 1) * (g.mz + 1) * ((g.mx + 256) / 256), 65536);
+			HIPCHK(hipMalloc((void **)&s.partial, s.partial_cap * sizeof(double)));
+			HIPCHK(hipMalloc((void **)&s.counter, 64));
+			HIPCHK(hipMemsetAsync(s.counter, 0, 64, s.st));
+			HIPCHK(hipMalloc((void **)&s.gather, sizeof(double) * KRY_NSUMS * KRY_MAX_SLABS));
+			HIPCHK(hipStreamSynchronize(s.st));
+		}
+		// peer access between the devices of neighbouring local slabs
+		for (int i = 0; i + 1 < d->slab_count; ++i) {
+			int a = h->slabs[i].device, b = h->slabs[i + 1].device;
+			if (a == b) continue;
+			hipSetDevice(a); hipDeviceEnablePeerAccess(b, 0);
+			hipSetDevice(b); hipDeviceEnablePeerAccess(a, 0);
+			(void)hipGetLastError();
+		}
+		return 0;
+	};
+	st = build();
+	if (st < 0) {
+		kry_destroy(h);
+		return fail(st);
+	}
+	if (status) *status = KRY_OK;
+	return h;
+}
+
+void kry_destroy(kry_handle h)
+{
+	if (!h) return;
+	h->comm.destroy();
+	for (Slab &s : h->slabs) {
+		hipSetDevice(s.device);
+		if (s.st) hipStreamSynchronize(s.st);
+		free_fields(s);
+		if (s.S) hipFree(s.S);
+		if (s.Sh) hipHostFree(s.Sh);
+		if (s.partial) hipFree(s.partial);
+		if (s.counter) hipFree(s.counter);
+		if (s.gather) hipFree(s.gather);
+		if (s.ev) hipEventDestroy(s.ev);
+		if (s.ev_in) hipEventDestroy(s.ev_in);
+		if (s.st) hipStreamDestroy(s.st);
+	}
+	for (hipEvent_t e : h->prof.ev) hipEventDestroy(e);
+	delete h;
+}
+
+int kry_comm_unique_id(void *uid)
+{
+	int st = KryComm::unique_id(uid);
+	if (st < 0) set_err("%s", KryComm::last_error());
+	return st;
+}
+
+int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks)
+{
+	if (!h || !uid) { set_err("null argument"); return KRY_ERR_ARG; }
+	if (h->d.slab_count != 1 || h->d.nslabs != nranks || h->d.slab_begin != rank) {
+		set_err("kry_comm_init: rank r must own exactly slab r (nslabs=%d begin=%d count=%d, rank=%d/%d)",
+		        h->d.nslabs, h->d.slab_begin, h->d.slab_count, rank, nranks);
+		return KRY_ERR_ARG;
+	}
+	hipSetDevice(h->slabs[0].device);
+	int st = h->comm.init(uid, rank, nranks);
+	if (st < 0) set_err("%s", KryComm::last_error());
+	return st;
+}
+
+int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda, double Dxx,
+                   double Dyy, double Dzz)
+{
+	if (!h) return KRY_ERR_ARG;
+	const double Dc[3] = {Dxx, Dyy, Dzz};
+	return load_common(h, false, false, Dc, phi, rhs, lambda, nullptr, nullptr, nullptr, nullptr);
+}
+
+int kry_load_var(kry_handle h, const double *phi, const double *rhs, const double *lambda, const double *Dxx,
+                 const double *Dyy, const double *Dzz, const double *Dxy, int use_offdiag)
+{
+	if (!h) return KRY_ERR_ARG;
+	const double Dc[3] = {1., 1., 1.};
+	return load_common(h, true, use_offdiag != 0, Dc, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy);
+}
+
+int kry_iterate(kry_handle h, int n_outer)
+{
+	if (!h) return KRY_ERR_ARG;
+	if (n_outer <= 0) { set_err("n_outer must be positive"); return KRY_ERR_ARG; }
+	return run_iterations(h, n_outer);
+}
+
+int kry_fetch_phi(kry_handle h, double *phi)
+{
+	if (!h || !phi) return KRY_ERR_ARG;
+	if (!h->loaded) { set_err("no problem loaded"); return KRY_ERR_STATE; }
+	return finish_solve(h, phi);
+}
+
+static int solve_tail(kry_handle h, double *phi, int debug)
+{
+	h->debug = debug;
+	int st = h->status;
+	if (st == 0 && !h->done) st = run_iterations(h, 0);
+	if (st < 0) return st;
+	if (debug > 2) {
+		printf(" Final error: %g after %d iterations \n", h->norm_final, h->it_base);
+		printf(" Norm: %g %g %g %g %d\n", h->norm_final, h->norm_final / h->norm_rhs, h->norm_rhs,
+		       h->d.eps * h->norm_rhs, h->it_base);
+	}
+	int st2 = finish_solve(h, phi);
+	return st2 < 0 ? st2 : st;
+}
+
+int kry_solve_const(kry_handle h, double *phi, const double *rhs, const double *lambda, double Dxx, double Dyy,
+                    double Dzz, int debug)
+{
+	if (!h) return KRY_ERR_ARG;
+	h->debug = debug;
+	int st = kry_load_const(h, phi, rhs, lambda, Dxx, Dyy, Dzz);
+	if (st < 0) return st;
+	return solve_tail(h, phi, debug);
+}
+
+int kry_solve_var(kry_handle h, double *phi, const double *rhs, const double *lambda, const double *Dxx,
+                  const double *Dyy, const double *Dzz, const double *Dxy, int use_offdiag, int debug)
+{
+	if (!h) return KRY_ERR_ARG;
+	h->debug = debug;
+	int st = kry_load_var(h, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy, use_offdiag);
+	if (st < 0) return st;
+	return solve_tail(h, phi, debug);
+}
+
+int kry_get_stats(kry_handle h, kry_stats *o)
+{
+	if (!h || !o) return KRY_ERR_ARG;
+	memset(o, 0, sizeof *o);
+	o->status = h->status;
+	o->iterations = h->it_base;
+	o->fused = h->fused ? 1 : 0;
+	o->norm_rhs = h->norm_rhs;
+	o->norm_init = h->norm_init;
+	o->norm_final = h->norm_final;
+	o->solve_ms = h->solve_ms;
+	o->stage_ms = h->stage_ms;
+	// algorithmic doubles moved per grid point and outer pass under the fully fused schedule
+	int W;
+	if (h->L == 1) W = h->var ? (h->offd ? 28 : 26) : 20;
+	else if (h->L == 2) W = h->var ? (h->offd ? 66 : 62) : 50;
+	else W = 0;
+	const double npts = (double)(h->d.mx[0] + 1) * (h->d.mx[1] + 1) * ((double)h->mzl * h->d.nslabs + 1);
+	o->bytes_per_iter = 8.0 * W * npts;
+	for (int k = 0; k < 8; ++k) { o->kernel_ms[k] = h->kernel_ms[k]; o->kernel_calls[k] = h->kernel_calls[k]; }
+	return 0;
+}
+
+int kry_get_history(kry_handle h, double *norms, int cap)
+{
+	if (!h || (!norms && cap > 0)) return KRY_ERR_ARG;
+	int n = h->it_base;
+	if (h->fused) {
+		n = std::min(n, KRY_HIST_CAP);
+		int m = std::min(n, cap);
+		if (m > 0) {
+			Slab &s = h->slabs[0];
+			hipSetDevice(s.device);
+			if (hipMemcpy(norms, s.S->hist, (size_t)m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+				set_err("history copy failed");
+				return KRY_ERR_HIP;
+			}
+		}
+		return n;
+	}
+	n = (int)h->hist.size();
+	for (int i = 0; i < std::min(n, cap); ++i) norms[i] = h->hist[i];
+	return n;
+}
+
+// ------------------------------------------------------ single operators
+
+static int op_prepare(kry_handle h, bool var, bool offd, const double Dc[3])
+{
+	h->var = var;
+	h->offd = var && offd;
+	make_op(h, var, Dc);
+	return 0;
+}
+
+int kry_op_do_bcs(kry_handle h, double *field)
+{
+	if (!h || !field) return KRY_ERR_ARG;
+	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(upload(h, h->slabs[i], (int)i, h->slabs[i].phi, field));
+	CHK(g_do_bcs(h, &Slab::phi));
+	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(download(h, h->slabs[i], (int)i, h->slabs[i].phi, field));
+	return sync_all(h);
+}
+
+static int op_spmv(kry_handle h, double *psi, bool psi_mutable, const double *lambda, double *out, int apply_bcs,
+                   int fused)
+{
+	bool dirichlet = true;
+	for (int f = 0; f < 6; ++f) dirichlet = dirichlet && (h->d.bc_type[f] == 0);
+	if (fused && !dirichlet) { set_err("fused operator needs Dirichlet faces"); return KRY_ERR_ARG; }
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		CHK(upload(h, s, (int)i, s.phi, psi));
+		CHK(upload(h, s, (int)i, s.lam, lambda));
+		CHK(zero_field(s, s.rb[0][0]));
+	}
+	auto in = ptrs(h, &Slab::phi), o = ptrs_r(h, 0);
+	if (fused) {
+		if (!h->var) CHK(g_do_bcs(h, &Slab::phi));
+		for (size_t i = 0; i < h->slabs.size(); ++i) {
+			Slab &s = h->slabs[i];
+			KryFused a = fused_base(h, s, PH_NONE);
+			a.X = s.phi.p;
+			a.O = s.rb[0][0].p;
+			CHK(launch_fused(h, s, KF_SPMV, a));
+		}
+		CHK(exchange_halo(h, o));
+		(void)apply_bcs;   // Dirichlet output faces stay zero by construction
+	} else {
+		CHK(g_spmv(h, in, o, apply_bcs != 0));
+	}
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		CHK(download(h, s, (int)i, s.rb[0][0], out));
+		if (psi_mutable) CHK(download(h, s, (int)i, s.phi, psi));
+	}
+	return sync_all(h);
+}
+
+int kry_op_spmv_const(kry_handle h, double *psi, const double *lambda, double Dxx, double Dyy, double Dzz,
+                      double *out, int apply_bcs, int fused)
+{
+	if (!h || !psi || !lambda || !out) return KRY_ERR_ARG;
+	const double Dc[3] = {Dxx, Dyy, Dzz};
+	op_prepare(h, false, false, Dc);
+	return op_spmv(h, psi, true, lambda, out, apply_bcs, fused);
+}
+
+int kry_op_spmv_var(kry_handle h, const double *psi, const double *lambda, const double *Dxx, const double *Dyy,
+                    const double *Dzz, const double *Dxy, int use_offdiag, double *out, int apply_bcs, int fused)
+{
+	if (!h || !psi || !lambda || !out || !Dxx || !Dyy || !Dzz || (use_offdiag && !Dxy)) return KRY_ERR_ARG;
+	const double Dc[3] = {1., 1., 1.};
+	op_prepare(h, true, use_offdiag != 0, Dc);
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		CHK(upload(h, s, (int)i, s.Dxx, Dxx));
+		CHK(upload(h, s, (int)i, s.Dyy, Dyy));
+		CHK(upload(h, s, (int)i, s.Dzz, Dzz));
+		if (use_offdiag) CHK(upload(h, s, (int)i, s.Dxy, Dxy));
+	}
+	return op_spmv(h, const_cast<double *>(psi), false, lambda, out, apply_bcs, fused);
+}
+
+static int op_dot(kry_handle h, const double *a, const double *b, int norm_mode, double *result)
+{
+	for (size_t i = 0; i < h->slabs.size(); ++i) {
+		Slab &s = h->slabs[i];
+		CHK(upload(h, s, (int)i, s.phi, a));
+		CHK(upload(h, s, (int)i, s.rhs, b));
+	}
+	auto x = ptrs(h, &Slab::phi), y = ptrs(h, &Slab::rhs);
+	double v;
+	CHK(g_dot(h, x, y, norm_mode, &v));
+	*result = norm_mode ? std::sqrt(v) : v;
+	return 0;
+}
+
+int kry_op_dot(kry_handle h, const double *a, const double *b, double *result)
+{
+	if (!h || !a || !b || !result) return KRY_ERR_ARG;
+	return op_dot(h, a, b, 0, result);
+}
+
+int kry_op_l2norm(kry_handle h, const double *v, double *result)
+{
+	if (!h || !v || !result) return KRY_ERR_ARG;
+	return op_dot(h, v, v, 1, result);
+}
+
+} // extern "C"

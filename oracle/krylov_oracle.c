@@ -20,6 +20,14 @@
 #include <string.h>
 #include <sys/time.h>
 
+/* Accumulator type of the reductions.  The reference accumulates in double
+ * (Krylov.C:70,169); building with -DORC_ACC="long double" gives a variant
+ * that differs from it in summation rounding only, used to measure how
+ * strongly a residual history reacts to that rounding. */
+#ifndef ORC_ACC
+#define ORC_ACC double
+#endif
+
 /* ---- ghost-inclusive indexing ------------------------------------------ */
 
 typedef struct {
@@ -196,7 +204,7 @@ double orc_l2norm(const orc_cfg *c, const double *v)
 	if (valMax == 0.) return 0;
 	double scaleFactor = 1. / valMax;
 
-	double sum = 0.;
+	ORC_ACC sum = 0.;
 	for (int iz = 1; iz < mz; iz++)
 		for (int iy = 1; iy < my; iy++)
 			for (int ix = 1; ix < mx; ix++) {
@@ -249,7 +257,7 @@ double orc_l2norm(const orc_cfg *c, const double *v)
 	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, 0, mz));
 	sum += 0.25 * sqr(scaleFactor * AT(b, v, mx, my, mz));
 
-	return valMax * sqrt(sum);
+	return valMax * sqrt((double)sum);
 }
 
 /* ---- Krylov::dot_product, BICGStab3D/Krylov.C:161-244 --------------------- */
@@ -257,7 +265,7 @@ double orc_dot(const orc_cfg *c, const double *A, const double *B)
 {
 	const box_t b = box_of(c);
 	const int mx = b.mx, my = b.my, mz = b.mz;
-	double result = 0.;
+	ORC_ACC result = 0.;
 
 	for (int iz = 1; iz < mz; iz++)
 		for (int iy = 1; iy < my; iy++)
@@ -307,7 +315,7 @@ double orc_dot(const orc_cfg *c, const double *A, const double *B)
 	result += 0.125 * AT(b, A, mx, 0, mz) * AT(b, B, mx, 0, mz);
 	result += 0.125 * AT(b, A, 0, my, mz) * AT(b, B, 0, my, mz);
 	result += 0.125 * AT(b, A, mx, my, mz) * AT(b, B, mx, my, mz);
-	return result;
+	return (double)result;
 }
 
 /* ---- Krylov::multiply_withMat, constant coefficients ----------------------
