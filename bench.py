@@ -50,6 +50,21 @@ def kernel_words(L, var, offd):
             7: 11}                 # phi,r0..r2,u0..u2,rt -> phi,r0,u0
 
 
+def measured_traffic(kernel_name, n, L, workload, world):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes
+    (profiles/*_hbm_traffic.json), if they were taken on this very workload."""
+    import glob
+    want = "%d^3 fp64 %s-coefficient, l=%d, %d GPU" % (n, "variable" if workload == "var" else "constant", L, world)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == want and kernel_name in d.get("kernels", {}):
+            return d["kernels"][kernel_name]["hbm_bytes_per_launch"], os.path.basename(path)
+    return None, None
+
+
 def slab_problem(n, nslabs, slab, workload):
     """Fields of z-slab `slab` of the n^3 problem, ghost planes included,
     evaluated from closed forms at global positions."""
@@ -144,8 +159,9 @@ def main():
         sys.exit("grid size %d is not divisible by %d slabs" % (n, world))
     f = slab_problem(n, world, rank, args.workload)
 
+    device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank))
     solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
-                         slab_begin=rank, slab_count=1, devices=(local_rank,))
+                         slab_begin=rank, slab_count=1, devices=(device,))
     if world > 1:
         import torch
         uid = [capi.unique_id() if rank == 0 else None]
@@ -201,6 +217,10 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4),
                     "traffic": None, "avg_launch_ms": round(kern[dom]["avg_ms"], 4),
                     "algorithmic_bytes_per_launch": 8.0 * kern[dom]["words"] * npts / world}
+            tr, src = measured_traffic(kern[dom]["name"], n, L, args.workload, world)
+            if tr is not None:
+                roof["traffic"] = tr
+                roof["traffic_source"] = "profiles/" + src
         ms_step = elapsed / args.steps * 1e3
         W = {1: (26 if var else 20), 2: (62 if var else 50)}[L]
         whole = 8.0 * W * npts / (ms_step * 1e-3) / 1e9
