@@ -125,11 +125,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=512, help="grid size (points 0..n per direction)")
-    ap.add_argument("--L", type=int, default=2, help="BiCGStab(l) degree; the reference drivers use 2")
+    ap.add_argument("--grid", dest="n", type=int, default=512, help="grid size (points 0..n per direction)")
+    ap.add_argument("--ell", dest="L", type=int, default=2, help="BiCGStab(l) degree; the reference drivers use 2")
     ap.add_argument("--workload", choices=["var", "const"], default="var")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-n", type=int, default=192)
+    ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=192)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
 
