@@ -76,6 +76,9 @@ typedef struct kry_stats {
 	double bytes_per_iter;   /* algorithmic bytes: 8 * W * N_pts of the global grid */
 	double kernel_ms[8];     /* HIP-event time per fused kernel kind, summed over calls */
 	int    kernel_calls[8];
+	int    tile_rows;        /* launch geometry, which fixes the summation order of the dots: */
+	int    chunk_planes;     /*   rows per fused tile, planes per fused chunk,               */
+	int    stream_blocks;    /*   grid target of the streaming kernels                        */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;

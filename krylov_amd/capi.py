@@ -57,6 +57,9 @@ class KryStats(C.Structure):
         ("bytes_per_iter", C.c_double),
         ("kernel_ms", C.c_double * 8),
         ("kernel_calls", C.c_int * 8),
+        ("tile_rows", C.c_int),
+        ("chunk_planes", C.c_int),
+        ("stream_blocks", C.c_int),
     ]
 
 
@@ -256,4 +259,5 @@ def solve_problem(p, L=2, eps=1e-6, max_outer=0, flags=0, nslabs_local=1, device
         hist = s.history()
     return dict(status=st, phi=phi, history=hist, iters=stats.iterations, norm_rhs=stats.norm_rhs,
                 norm_init=stats.norm_init, norm_final=stats.norm_final, fused=bool(stats.fused),
-                solve_ms=stats.solve_ms, stage_ms=stats.stage_ms)
+                solve_ms=stats.solve_ms, stage_ms=stats.stage_ms,
+                order=(stats.tile_rows, stats.chunk_planes, stats.stream_blocks))

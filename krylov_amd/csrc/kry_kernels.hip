@@ -533,26 +533,23 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				if (KIND == KF_RES) a.O2[p + 1] = out.y;
 			}
 			// dot products over counted interior points
-			const double w0 = (m0 && cnt) ? 1. : 0., w1 = (m1 && cnt) ? 1. : 0.;
+			const bool c0 = m0 && cnt, c1 = m1 && cnt;
+			auto add = [&](double &s, double vx, double vy) {
+				s += c0 ? vx : 0.;
+				s += c1 ? vy : 0.;
+			};
 			if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
 				const double2 rt = ld2(a.RT + p);
-				acc[0] += w0 * (out.x * rt.x);
-				acc[0] += w1 * (out.y * rt.y);
+				add(acc[0], out.x * rt.x, out.y * rt.y);
 			} else if (KIND == KF_B0L) {
-				acc[0] += w0 * (pc[e].x * out.x);
-				acc[0] += w1 * (pc[e].y * out.y);
-				acc[1] += w0 * (out.x * out.x);
-				acc[1] += w1 * (out.y * out.y);
+				add(acc[0], pc[e].x * out.x, pc[e].y * out.y);
+				add(acc[1], out.x * out.x, out.y * out.y);
 			} else if (KIND == KF_B1L) {
-				acc[0] += w0 * (pc[e].x * pc[e].x);
-				acc[0] += w1 * (pc[e].y * pc[e].y);
-				acc[1] += w0 * (comp.x * pc[e].x);
-				acc[1] += w1 * (comp.y * pc[e].y);
-				acc[2] += w0 * (out.x * pc[e].x);
-				acc[2] += w1 * (out.y * pc[e].y);
+				add(acc[0], pc[e].x * pc[e].x, pc[e].y * pc[e].y);
+				add(acc[1], comp.x * pc[e].x, comp.y * pc[e].y);
+				add(acc[2], out.x * pc[e].x, out.y * pc[e].y);
 			} else if (KIND == KF_RES) {
-				acc[0] += w0 * (out.x * out.x);
-				acc[0] += w1 * (out.y * out.y);
+				add(acc[0], out.x * out.x, out.y * out.y);
 			}
 		}
 		// 4. rotate the z pipeline

@@ -1172,6 +1172,9 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	const double npts = (double)(h->d.mx[0] + 1) * (h->d.mx[1] + 1) * ((double)h->mzl * h->d.nslabs + 1);
 	o->bytes_per_iter = 8.0 * W * npts;
 	for (int k = 0; k < 8; ++k) { o->kernel_ms[k] = h->kernel_ms[k]; o->kernel_calls[k] = h->kernel_calls[k]; }
+	o->tile_rows = h->ty;
+	o->chunk_planes = h->zc;
+	o->stream_blocks = h->stream_blocks;
 	return 0;
 }
 

@@ -1,0 +1,208 @@
+/*
+ * gpu_order.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Repeats the dot products and norms of the oracle's solve in the summation
+ * order of the HIP kernels (krylov_amd/csrc/kry_kernels.hip).  Everything else
+ * in the solve stays the line-faithful restatement of the reference; with this
+ * hook installed the oracle and the device differ in nothing, so their residual
+ * histories can be compared bit for bit.  Run without the hook, the same oracle
+ * sums in the reference's order (Krylov.C:161-244); the two runs differ through
+ * summation order only.
+ *
+ * Orders reproduced (256-thread blocks, 4 wavefronts of 64 lanes):
+ *   per thread   products added in the order the kernel visits its points
+ *   per wave     shuffle tree: v[i] += v[i+o], o = 32,16,8,4,2,1
+ *   per block    wave sums added in wave order
+ *   grid         thread t adds partials t, t+256, ...; then wave tree; then waves
+ * Three kernel shapes exist: the fused stencil kernels (tiles of 128 x ty points
+ * marched over zc planes, XCD-swizzled block order), the streaming kernels
+ * (2048-double plane segments x plane groups) and the generic weighted dot (one
+ * block per 256 points of a grid row).
+ */
+#include "krylov_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#define NT 256
+#define NW 4
+
+static int g_mode = 0;          /* 0 off, 1 fused path, 2 generic path */
+static int g_ty = 8, g_zc = 16, g_sb = 2048;
+
+typedef struct { int mx, my, mz; long sx, sy; } hbox;
+static hbox hb(const orc_cfg *c)
+{
+	hbox b;
+	b.mx = c->mx[0]; b.my = c->mx[1]; b.mz = c->mx[2];
+	b.sx = b.mx + 3;
+	b.sy = b.sx * (long)(b.my + 3);
+	return b;
+}
+#define HAT(b, a, i, j, k) ((a)[((long)(k) + 1) * (b).sy + ((long)(j) + 1) * (b).sx + ((i) + 1)])
+
+static double wave_tree(double *v)
+{
+	for (int o = 32; o > 0; o >>= 1)
+		for (int i = 0; i < o; ++i) v[i] = v[i] + v[i + o];
+	return v[0];
+}
+
+static double block_total(double *thread_acc /* NT */)
+{
+	double w[NW];
+	for (int k = 0; k < NW; ++k) w[k] = wave_tree(thread_acc + 64 * k);
+	double v = w[0];
+	for (int k = 1; k < NW; ++k) v += w[k];
+	return v;
+}
+
+static double grid_total(const double *partial, long nblk)
+{
+	double tot[NT];
+	for (int t = 0; t < NT; ++t) {
+		double s = 0.;
+		for (long b = t; b < nblk; b += NT) s += partial[b];
+		tot[t] = s;
+	}
+	return block_total(tot);
+}
+
+/* fused stencil kernels: k_fused */
+static double fused_sum(const orc_cfg *c, const double *A, const double *B)
+{
+	const hbox b = hb(c);
+	const int ty = g_ty, zc = g_zc, VD = ty / NW;
+	const int ntx = (b.mx + 127) / 128, nty = (b.my + ty - 1) / ty;
+	const int zlo = 1, zhi = b.mz - 1;
+	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
+	const long nblk = (long)ntx * nty * nchunk;
+	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
+	for (long bp = 0; bp < nblk; ++bp) {
+		const long q = nblk >> 3, r = nblk & 7, x = bp & 7;
+		const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
+		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
+		const int z0 = zlo + ch * zc;
+		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
+		const int y0 = tyi * ty;
+		double acc[NT];
+		for (int t = 0; t < NT; ++t) {
+			const int w = t >> 6, lane = t & 63;
+			const int i0 = 128 * tx + 2 * lane;
+			double s = 0.;
+			for (int z = z0; z < z1; ++z)
+				for (int e = 0; e < VD; ++e) {
+					const int j = y0 + w * VD + e;
+					if (j < 1 || j > b.my - 1 || z < 1) continue;
+					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, z) * HAT(b, B, i0, j, z);
+					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, z) * HAT(b, B, i0 + 1, j, z);
+				}
+			acc[t] = s;
+		}
+		partial[bp] = block_total(acc);
+	}
+	double v = grid_total(partial, nblk);
+	free(partial);
+	return v;
+}
+
+/* streaming kernels: k_final, k_mgs2 */
+static double stream_sum(const orc_cfg *c, const double *A, const double *B)
+{
+	const hbox b = hb(c);
+	const long px = ((b.mx + 4 + 15) / 16) * 16, ps = px * (b.my + 3);
+	const int nbx = (int)((ps + 2047) / 2048);
+	const int nplanes = b.mz - 1;
+	int nby = (g_sb + nbx - 1) / nbx;
+	if (nby > nplanes) nby = nplanes;
+	if (nby < 1) nby = 1;
+	const long nblk = (long)nbx * nby;
+	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
+	for (int by = 0; by < nby; ++by)
+		for (int bx = 0; bx < nbx; ++bx) {
+			double acc[NT];
+			for (int t = 0; t < NT; ++t) {
+				double s = 0.;
+				for (int pl = by; pl < nplanes; pl += nby) {
+					const int z = 1 + pl;
+					for (int i = 0; i < 4; ++i) {
+						const long q = 2 * ((long)bx * 1024 + i * NT + t);
+						if (q >= ps) break;
+						for (int d = 0; d < 2; ++d) {
+							const long qq = q + d;
+							const int jj = (int)(qq / px) - 1, ii = (int)(qq % px) - 2;
+							if (ii >= 1 && ii <= b.mx - 1 && jj >= 1 && jj <= b.my - 1)
+								s += HAT(b, A, ii, jj, z) * HAT(b, B, ii, jj, z);
+						}
+					}
+				}
+				acc[t] = s;
+			}
+			partial[bx + (long)nbx * by] = block_total(acc);
+		}
+	double v = grid_total(partial, nblk);
+	free(partial);
+	return v;
+}
+
+/* generic weighted dot: g_wdot */
+static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int norm_mode)
+{
+	const hbox b = hb(c);
+	const int gx = (b.mx + 1 + NT - 1) / NT, gy = b.my + 1, gz = b.mz + 1;
+	const long nblk = (long)gx * gy * gz;
+	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
+	for (int k = 0; k < gz; ++k)
+		for (int j = 0; j < gy; ++j)
+			for (int bx = 0; bx < gx; ++bx) {
+				double acc[NT];
+				for (int t = 0; t < NT; ++t) {
+					const int i = bx * NT + t;
+					double s = 0.;
+					if (i <= b.mx) {
+						const int fx = (i == 0 || i == b.mx), fy = (j == 0 || j == b.my), fz = (k == 0 || k == b.mz);
+						double wgt = (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
+						if (norm_mode && fx && fy && fz) wgt = 0.25;
+						s = wgt * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
+					}
+					acc[t] = s;
+				}
+				partial[bx + (long)gx * (j + (long)gy * k)] = block_total(acc);
+			}
+	double v = grid_total(partial, nblk);
+	free(partial);
+	return v;
+}
+
+static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b)
+{
+	(void)ctx;
+	if (g_mode == 2) {   /* generic path: every reduction is a g_wdot launch */
+		if (site == ORC_SITE_NORM_RHS || site == ORC_SITE_NORM_INIT || site == ORC_SITE_NORM)
+			return sqrt(wdot_sum(c, a, b, 1));
+		return wdot_sum(c, a, b, 0);
+	}
+	switch (site) {
+	case ORC_SITE_NORM_RHS:  return sqrt(wdot_sum(c, a, b, 1));
+	case ORC_SITE_NORM_INIT: return sqrt(fused_sum(c, a, b));          /* residual kernel */
+	case ORC_SITE_RHO:
+		if (jj == 0) return iter == 1 ? fused_sum(c, a, b)                /* |r0|^2 of the residual kernel */
+		                              : stream_sum(c, a, b);              /* end-of-pass kernel */
+		return fused_sum(c, a, b);                                        /* B kernel of jj-1 */
+	case ORC_SITE_ALPHA:     return fused_sum(c, a, b);                   /* A kernels */
+	case ORC_SITE_TAU:       return fused_sum(c, a, b);                   /* last B kernel */
+	case ORC_SITE_SIGMA:
+	case ORC_SITE_GAMMAP:    return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b);
+	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b));
+	}
+	return orc_dot(c, a, b);
+}
+
+void orc_use_gpu_order(int enable, int ty, int zc, int stream_blocks)
+{
+	g_mode = enable;
+	if (ty > 0) g_ty = ty;
+	if (zc > 0) g_zc = zc;
+	if (stream_blocks > 0) g_sb = stream_blocks;
+	orc_set_reduce_hook(enable ? hook : NULL, NULL);
+}

@@ -28,6 +28,31 @@
 #define ORC_ACC double
 #endif
 
+/* ---- optional reduction hook ---------------------------------------------
+ * When set, every dot product / norm of orc_solve is delegated to the hook,
+ * which receives the call site.  gpu_order.c uses it to repeat the sums in the
+ * order of the device kernels; everything else in the solve stays as is. */
+static orc_reduce_hook g_hook = NULL;
+static void *g_hook_ctx = NULL;
+
+void orc_set_reduce_hook(orc_reduce_hook hook, void *ctx)
+{
+	g_hook = hook;
+	g_hook_ctx = ctx;
+}
+
+static double site_dot(int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b)
+{
+	if (g_hook) return g_hook(g_hook_ctx, site, iter, jj, c, a, b);
+	return orc_dot(c, a, b);
+}
+
+static double site_norm(int site, int iter, const orc_cfg *c, const double *v)
+{
+	if (g_hook) return g_hook(g_hook_ctx, site, iter, 0, c, v, v);
+	return orc_l2norm(c, v);
+}
+
 /* ---- ghost-inclusive indexing ------------------------------------------ */
 
 typedef struct {
@@ -445,7 +470,7 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 		Dxx = Dyy = Dzz = Dxy = rhs;
 	}
 
-	double normRHS = orc_l2norm(c, rhs);                     /* :268 */
+	double normRHS = site_norm(ORC_SITE_NORM_RHS, 0, c, rhs);   /* :268 */
 	if (normRHS == 0.) normRHS = 1.;                         /* :269 */
 	o.norm_rhs = normRHS;
 
@@ -460,7 +485,7 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 
 	int iter_steps = 0;
 	residual(c, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy, r[0]); /* :294-299 */
-	double norm_init = orc_l2norm(c, r[0]);                  /* :301 */
+	double norm_init = site_norm(ORC_SITE_NORM_INIT, 0, c, r[0]);   /* :301 */
 	o.norm_init = norm_init;
 
 	double norm = 1.e99;
@@ -502,7 +527,7 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 
 			/* BiCG part, :345-410 */
 			for (int jj = 0; jj < L; ++jj) {
-				rho1 = orc_dot(c, r[jj], rt);                /* :349 */
+				rho1 = site_dot(ORC_SITE_RHO, iter_steps, jj, c, r[jj], rt);   /* :349 */
 				double beta = alpha * rho1 / rho0;           /* :351 */
 				rho0 = rho1;
 
@@ -513,7 +538,7 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 
 				spmv(c, u[jj], lambda, Dxx, Dyy, Dzz, Dxy, u[jj + 1]);   /* :374-378 */
 
-				alpha = rho0 / orc_dot(c, u[jj + 1], rt);    /* :390 */
+				alpha = rho0 / site_dot(ORC_SITE_ALPHA, iter_steps, jj, c, u[jj + 1], rt);   /* :390 */
 
 				for (int ii = 0; ii <= jj; ++ii)             /* :392-394 */
 					arr_sub_scaled(n, r[ii], u[ii + 1], alpha);
@@ -532,11 +557,11 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 			/* MR part, :419-430 */
 			for (int jj = 1; jj <= L; ++jj) {
 				for (int ii = 1; ii < jj; ++ii) {
-					tau[ii][jj] = orc_dot(c, r[jj], r[ii]) / sigma[ii];
+					tau[ii][jj] = site_dot(ORC_SITE_TAU, iter_steps, jj, c, r[jj], r[ii]) / sigma[ii];
 					arr_sub_scaled(n, r[jj], r[ii], tau[ii][jj]);
 				}
-				sigma[jj] = orc_dot(c, r[jj], r[jj]);
-				gammap[jj] = orc_dot(c, r[0], r[jj]) / sigma[jj];
+				sigma[jj] = site_dot(ORC_SITE_SIGMA, iter_steps, jj, c, r[jj], r[jj]);
+				gammap[jj] = site_dot(ORC_SITE_GAMMAP, iter_steps, jj, c, r[0], r[jj]) / sigma[jj];
 			}
 			omega = gamma[L] = gammap[L];                    /* :431 */
 
@@ -559,7 +584,7 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 				arr_sub_scaled(n, r[0], r[jj], gammap[jj]);
 			}
 
-			norm = orc_l2norm(c, r[0]);                      /* :464 */
+			norm = site_norm(ORC_SITE_NORM, iter_steps, c, r[0]);   /* :464 */
 			if (hist && iter_steps <= hist_cap) hist[iter_steps - 1] = norm;
 			if (c->debug > 2)                                /* :465-469 */
 				printf(" My error norm: %g %g %g %g %g \n", norm, sqrt(norm), eps * normRHS, eps,

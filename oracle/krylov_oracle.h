@@ -59,6 +59,30 @@ int orc_solve(const orc_cfg *cfg, double *phi, double *rhs, double *lambda,
               double *Dxx, double *Dyy, double *Dzz, double *Dxy,
               double *hist, int hist_cap, orc_out *out);
 
+/* Reduction call sites of orc_solve, for orc_set_reduce_hook. */
+enum {
+	ORC_SITE_NORM_RHS = 0,  /* l2(rhs)                     solveLin_BICGStab.C:268 */
+	ORC_SITE_NORM_INIT,     /* l2(first residual)          :301 */
+	ORC_SITE_RHO,           /* (r[jj], r~)                 :349 */
+	ORC_SITE_ALPHA,         /* (u[jj+1], r~)               :390 */
+	ORC_SITE_TAU,           /* (r[jj], r[ii])              :422 */
+	ORC_SITE_SIGMA,         /* (r[jj], r[jj])              :427 */
+	ORC_SITE_GAMMAP,        /* (r[0], r[jj])               :428 */
+	ORC_SITE_NORM           /* l2(r[0]) at the end of a pass :464 */
+};
+
+/* A hook replaces the summation of every reduction in orc_solve (norm sites must
+ * return the norm itself, not its square).  iter counts passes from 1; jj is the
+ * loop index of the site.  NULL restores the reference's summation order. */
+typedef double (*orc_reduce_hook)(void *ctx, int site, int iter, int jj, const orc_cfg *cfg,
+                                  const double *a, const double *b);
+void orc_set_reduce_hook(orc_reduce_hook hook, void *ctx);
+
+/* gpu_order.c: repeat the sums in the order of the HIP kernels (fused tile rows
+ * `ty`, planes per chunk `zc`, streaming-kernel grid target `stream_blocks`);
+ * enable = 0 switches back to the reference order. */
+void orc_use_gpu_order(int enable, int ty, int zc, int stream_blocks);
+
 /* Building blocks, exported for kernel-level parity tests. */
 void   orc_do_bcs(const orc_cfg *cfg, double *a);
 void   orc_spmv_const(const orc_cfg *cfg, double *psi, const double *lambda,

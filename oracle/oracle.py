@@ -41,9 +41,9 @@ class OrcOut(C.Structure):
 
 def build(force=False):
     """Compile the oracle with the committed Makefile (gcc only)."""
-    src = os.path.join(_HERE, "krylov_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("krylov_oracle.c", "gpu_order.c", "krylov_oracle.h")]
     if (not force and os.path.exists(_LIB)
-            and os.path.getmtime(_LIB) >= os.path.getmtime(src)):
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
         return _LIB
     subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -75,6 +75,8 @@ def lib():
         L.orc_l2norm.argtypes = [P(OrcCfg), _dp]
         L.orc_really_is_nan.restype = C.c_int
         L.orc_really_is_nan.argtypes = [C.c_double]
+        L.orc_use_gpu_order.restype = None
+        L.orc_use_gpu_order.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_store_size.restype = C.c_long
         L.orc_store_size.argtypes = [P(OrcCfg)]
         _lib = L
@@ -137,6 +139,12 @@ def dot(cfg, a, b):
 
 def l2norm(cfg, v):
     return lib().orc_l2norm(C.byref(cfg), v)
+
+
+def use_gpu_order(mode, ty=8, zc=16, stream_blocks=2048):
+    """mode 0: reference summation order; 1: order of the fused device path;
+    2: order of the generic device path (see gpu_order.c)."""
+    lib().orc_use_gpu_order(int(mode), int(ty), int(zc), int(stream_blocks))
 
 
 def really_is_nan(x):
