@@ -1,0 +1,48 @@
+// LinSolver3D.hpp -- abstract 3D linear-solver interface of the drop-in surface.
+//
+// Signature-compatible with the reference's Linsolver3D
+// (BICGStab3D/LinSolver3D.hpp:17-62): drivers written against it compile
+// unchanged.  Solves  div(D grad phi) - lambda*phi = rhs  on a uniform grid with
+// one ghost layer.
+#ifndef KRYLOV_AMD_LINSOLVER3D_HPP
+#define KRYLOV_AMD_LINSOLVER3D_HPP
+
+#include "BoundaryHandler.H"
+#include "grid_manager.H"
+#include "matrix.H"
+
+class Linsolver3D {
+public:
+	Linsolver3D() : my_type(0), dim(3), rank(0), debug(0) {}
+	virtual ~Linsolver3D() { my_type = -1; }
+
+	virtual void setup(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid, double epsilon_, NumArray<int> &solverPars,
+	                   bool spatial_diffusion, bool allow_offDiagDiffusion, int maxIter = 0) = 0;
+
+	// constant diagonal diffusion tensor
+	virtual void solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
+	                   NumMatrix<double, 3> &lambda, double D_xx, double D_yy, double D_zz, int debug = 0,
+	                   double delt = 0., bool evolve_time = false) = 0;
+	// diagonal diffusion tensor fields
+	virtual void solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
+	                   NumMatrix<double, 3> &lambda, NumMatrix<double, 3> &Dxx, NumMatrix<double, 3> &Dyy,
+	                   NumMatrix<double, 3> &Dzz, int debug = 0, double delt = 0., bool evolve_time = false) = 0;
+	// diffusion tensor fields with the xy off-diagonal element
+	virtual void solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
+	                   NumMatrix<double, 3> &lambda, NumMatrix<double, 3> &Dxx, NumMatrix<double, 3> &Dyy,
+	                   NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug = 0,
+	                   bool use_offDiagDiffusion = false, double delt = 0., bool evolve_time = false) = 0;
+	virtual void set_Advection(NumMatrix<double, 3> &ux_fine, BoundaryHandler3D &bounds, int dir) = 0;
+
+	int my_type;   // 20: BiCGStab (BICGStab3D/solveLin_BICGStab.C:117)
+
+protected:
+	virtual void solve_int(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
+	                       NumMatrix<double, 3> &lambda, NumMatrix<double, 3> &Dxx, NumMatrix<double, 3> &Dyy,
+	                       NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug = 0) = 0;
+	virtual void set_Grid(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid) = 0;
+	int dim, rank;
+	int debug;
+};
+
+#endif

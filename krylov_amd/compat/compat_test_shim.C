@@ -1,0 +1,79 @@
+// C entry points over the host-side drop-in classes so that the Python tests can
+// exercise them (NumMatrix layout, grid geometry, BoundaryHandler3D::do_BCs on
+// host arrays, the BICGStab adaptor).
+#include <cstring>
+
+#include "BoundaryHandler.H"
+#include "grid_manager.H"
+#include "solveLin_BICGStab.H"
+
+namespace {
+void wrap(NumMatrix<double, 3> &m, const int mx[3], const double *src)
+{
+	m.resize(Index::set(-1, -1, -1), Index::set(mx[0] + 1, mx[1] + 1, mx[2] + 1));
+	if (src) memcpy(m.data(), src, m.size() * sizeof(double));
+}
+} // namespace
+
+extern "C" {
+
+// fills `a` (ghost-inclusive box, x fastest) through NumMatrix::operator()
+void compat_fill_ijk(const int mx[3], double *a)
+{
+	NumMatrix<double, 3> m;
+	wrap(m, mx, NULL);
+	for (int k = -1; k <= mx[2] + 1; ++k)
+		for (int j = -1; j <= mx[1] + 1; ++j)
+			for (int i = -1; i <= mx[0] + 1; ++i) m(i, j, k) = i + 100. * j + 10000. * k;
+	memcpy(a, m.data(), m.size() * sizeof(double));
+}
+
+void compat_do_bcs(const int mx[3], const int bc[6], double *a)
+{
+	NumMatrix<double, 3> m;
+	wrap(m, mx, a);
+	BoundaryHandler3D b;
+	for (int f = 0; f < 6; ++f) b.set_bcType(f, bc[f]);
+	b.do_BCs(m, 1);
+	memcpy(a, m.data(), m.size() * sizeof(double));
+}
+
+// geometry numbers that enter the operator
+void compat_grid(int N, double xb, double xe, double *delx_manager, double *del_1d, double *pos /* N+2 */)
+{
+	grid_manager g(xb, xb, xb, xe, xe, xe, N, N, N, 1);
+	grid_1D g1(xb, xe, N, 2, 0, true);
+	*delx_manager = g.get_delx(0);
+	*del_1d = g1.get_del();
+	for (int i = -1; i <= N; ++i) pos[i + 1] = g.get_Pos(0, i);
+}
+
+// full solve through the Linsolver3D interface; returns the pass count
+int compat_solve(const int mx[3], const int bc[6], int L, double eps, int max_iter, int var, int offd, const double Dc[3],
+                 double *phi, const double *rhs, const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
+                 const double *Dxy, double *hist, int hist_cap, int *fused)
+{
+	grid_1D gx(0, 1, mx[0] + 1, 2, 0, true), gy(0, 1, mx[1] + 1, 2, 0, true), gz(0, 1, mx[2] + 1, 2, 0, true);
+	BoundaryHandler3D b;
+	for (int f = 0; f < 6; ++f) b.set_bcType(f, bc[f]);
+	NumMatrix<double, 3> mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy;
+	wrap(mphi, mx, phi); wrap(mrhs, mx, rhs); wrap(mlam, mx, lam);
+	BICGStab s;
+	Linsolver3D *ls = &s;
+	NumArray<int> pars(1);
+	pars(0) = L;
+	ls->setup(gx, gy, gz, eps, pars, false, false, max_iter);
+	if (var) {
+		wrap(mDxx, mx, Dxx); wrap(mDyy, mx, Dyy); wrap(mDzz, mx, Dzz); wrap(mDxy, mx, Dxy);
+		ls->solve(b, mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy, 0, offd != 0);
+	} else {
+		ls->solve(b, mphi, mrhs, mlam, Dc[0], Dc[1], Dc[2], 0);
+	}
+	memcpy(phi, mphi.data(), mphi.size() * sizeof(double));
+	std::vector<double> h = s.residualHistory();
+	for (int i = 0; i < (int)h.size() && i < hist_cap; ++i) hist[i] = h[i];
+	*fused = s.usedFusedKernels() ? 1 : 0;
+	return s.iterations();
+}
+
+}

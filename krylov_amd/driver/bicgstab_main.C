@@ -1,0 +1,222 @@
+// bicgstab_main.C -- command-line driver for the MI355X BiCGStab(l) solver.
+//
+// Same job, options and printed results as the reference's drivers
+// (BICGStab3D/main.C:57-581 and, for --stats / -i / -p, BiCGStab3D_CL/main.cpp:
+// 102-144, 532-608): set up one of five manufactured problems with the analytic
+// solution sin(pi x) sin(pi y) sin(pi z) on [0,1]^3, solve it through the
+// Linsolver3D interface and report the l2 error against the analytic solution.
+//
+//   bicgstab [-n MX] [-t 1..5] [-r] [-l L] [-e TOL] [-i MAXITER] [--stats] [-q]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "../compat/BoundaryHandler.H"
+#include "../compat/LinSolver3D.hpp"
+#include "../compat/grid_manager.H"
+#include "../compat/solveLin_BICGStab.H"
+
+using namespace std;
+
+namespace {
+
+const double default_tolerance = 1e-6;      // BICGStab3D/main.C:16
+
+double randomf(double lo, double hi)
+{
+	// BICGStab3D/main.C:47-50
+	const double diff = hi - lo;
+	return lo + (double)rand() / (double)(RAND_MAX / diff);
+}
+
+struct Options {
+	int mx = 32;            // BICGStab3D/main.C:71
+	int test = 1;           // 1..5
+	bool randomize = false;
+	int L = 2;              // BICGStab3D/main.C:458
+	double tol = default_tolerance;
+	int max_iter = 0;
+	bool stats = false;
+	bool quiet = false;
+	unsigned seed = 12345;
+};
+
+void usage(const char *argv0)
+{
+	cout << "BiCGStab solver (MI355X)" << endl;
+	cout << "Usage: " << argv0 << " [OPTIONS]" << endl;
+	cout << "OPTIONS:" << endl;
+	cout << "    -h   --help                   Print program help" << endl;
+	cout << "    -n   --size MX                " << endl;
+	cout << "         --mx   MX                Define problem size" << endl;
+	cout << "    -t   --test TEST              Define test case (1-5)" << endl;
+	cout << "    -r   --randomize              Randomize input" << endl;
+	cout << "    -l   --lvalue L               BiCGStab(L), default 2" << endl;
+	cout << "    -e   --tolerance TOL          Relative tolerance, default 1e-6" << endl;
+	cout << "    -i   --iterations N           Stop after N outer iterations" << endl;
+	cout << "    -s   --seed SEED              Seed for --randomize" << endl;
+	cout << "         --stats                  Print one CSV row instead of the report" << endl;
+	cout << "    -q   --quiet                  No per-iteration output" << endl;
+}
+
+bool parse(int argc, char **argv, Options &o)
+{
+	for (int i = 1; i < argc; ++i) {
+		const string a = argv[i];
+		auto need = [&](const char *what) -> const char * {
+			if (i >= argc - 1) { cerr << "Missing argument: " << what << endl; exit(EXIT_FAILURE); }
+			return argv[++i];
+		};
+		if (a == "-h" || a == "--help") { usage(argv[0]); exit(EXIT_SUCCESS); }
+		else if (a == "-n" || a == "--size" || a == "--mx") o.mx = atoi(need("Size"));
+		else if (a == "-r" || a == "--randomize") o.randomize = true;
+		else if (a == "-t" || a == "--test") {
+			o.test = atoi(need("Test"));
+			if (o.test < 1 || o.test > 5) { cerr << "Illegal test number. Must be [1-5] " << endl; return false; }
+		} else if (a == "-l" || a == "--lvalue") o.L = atoi(need("L"));
+		else if (a == "-e" || a == "--tolerance") o.tol = atof(need("Tolerance"));
+		else if (a == "-i" || a == "--iterations") o.max_iter = atoi(need("Iterations"));
+		else if (a == "-s" || a == "--seed") o.seed = (unsigned)atol(need("Seed"));
+		else if (a == "--stats") o.stats = true;
+		else if (a == "-q" || a == "--quiet") o.quiet = true;
+		else if (!a.empty() && a[0] != '-') o.mx = atoi(a.c_str());
+		else { cerr << "Illegal argument: " << a << endl; return false; }
+	}
+	return true;
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+	Options opt;
+	if (!parse(argc, argv, opt)) return EXIT_FAILURE;
+	if (!opt.stats) cout << "Problem size: " << opt.mx << ", running test " << opt.test << endl;
+
+	const int N = opt.mx + 1;
+	grid_manager MyGrid(0., 0., 0., 1., 1., 1., N, N, N, 1);
+	grid_1D grid_x(0, 1, N, 2, 0, true), grid_y(0, 1, N, 2, 0, true), grid_z(0, 1, N, 2, 0, true);
+	for (int b = 0; b < 6; ++b) MyGrid.set_bcType(b, 0);
+
+	BoundaryHandler3D MyBounds;
+	MyBounds.set_bcType(0);                   // all faces Dirichlet (BICGStab3D/main.C:187)
+
+	const int m = opt.mx;
+	NumMatrix<double, 3> phi, phi_ana, rhs, lambda, D[4];
+	const Index lo = Index::set(-1, -1, -1), hi = Index::set(m + 1, m + 1, m + 1);
+	phi.resize(lo, hi); phi_ana.resize(lo, hi); rhs.resize(lo, hi); lambda.resize(lo, hi);
+	for (int k = 0; k < 4; ++k) D[k].resize(lo, hi);
+	D[0].set_constVal(1.); D[1].set_constVal(1.); D[2].set_constVal(1.); D[3].clear();
+
+	const double pi = M_PI;
+	double Diff[3] = {1., 1., 10.};           // BICGStab3D/main.C:223-229
+	double lambda_factor = 0.2, dfac[4] = {1., 1., 1., 1.};
+	if (opt.randomize) {                      // BICGStab3D/main.C:237-241
+		srand(opt.seed);
+		lambda_factor = randomf(0.1, 100.0);
+		for (int k = 0; k < 4; ++k) dfac[k] = randomf(0.1, 10.0);
+	}
+	const double DPar = 1., DPerp = 0.1;
+
+	for (int iz = 0; iz <= m; ++iz)
+		for (int iy = 0; iy <= m; ++iy)
+			for (int ix = 0; ix <= m; ++ix) {
+				const double x = MyGrid.get_Pos(0, ix), y = MyGrid.get_Pos(1, iy), z = MyGrid.get_Pos(2, iz);
+				const double sx = sin(pi * x), sy = sin(pi * y), sz = sin(pi * z);
+				const double cx = cos(pi * x), cy = cos(pi * y), cz = cos(pi * z);
+				const double ana = sx * sy * sz;
+				phi_ana(ix, iy, iz) = ana;
+				const double lam = lambda_factor * x * sqr(y) * z;
+				lambda(ix, iy, iz) = lam;
+				switch (opt.test) {
+				case 1:   // constant diagonal tensor (main.C:282-284)
+					rhs(ix, iy, iz) = -(sqr(pi) * (Diff[0] + Diff[1] + Diff[2]) + lam) * ana;
+					break;
+				case 2:   // Dxx = y, Dyy = x, Dzz = z (main.C:299-311)
+					D[0](ix, iy, iz) = dfac[0] * y; D[1](ix, iy, iz) = dfac[1] * x; D[2](ix, iy, iz) = dfac[2] * z;
+					rhs(ix, iy, iz) = -(sqr(pi) * (x + y + z) + lam) * ana + pi * sx * sy * cz;
+					break;
+				case 3: { // test 2 plus Dxy = A x^2 y z (main.C:344-357)
+					const double A = 0.1;
+					D[0](ix, iy, iz) = dfac[0] * y; D[1](ix, iy, iz) = dfac[1] * x; D[2](ix, iy, iz) = dfac[2] * z;
+					const double dxy = dfac[3] * A * sqr(x) * y * z;
+					D[3](ix, iy, iz) = dxy;
+					rhs(ix, iy, iz) = -(sqr(pi) * (x + y + z) + lam) * ana + pi * sx * sy * cz +
+					                  2. * dxy * sqr(pi) * cx * cy * sz + 2. * A * x * y * z * pi * sx * cy * sz +
+					                  A * sqr(x) * z * pi * cx * sy * sz;
+					break;
+				}
+				case 4: { // rotated anisotropic tensor (main.C:360-394)
+					const double ang = atan2(y, x), sa = sin(ang), ca = cos(ang);
+					const double dxx = dfac[0] * (DPar * sqr(sa) + DPerp * sqr(ca));
+					const double dyy = dfac[1] * (DPar * sqr(ca) + DPerp * sqr(sa));
+					const double dzz = dfac[2] * DPerp;
+					const double dxy = dfac[3] * (DPerp - DPar) * sa * ca;
+					D[0](ix, iy, iz) = dxx; D[1](ix, iy, iz) = dyy; D[2](ix, iy, iz) = dzz; D[3](ix, iy, iz) = dxy;
+					const double r2 = sqr(x) + sqr(y);
+					const double dadx = -y / r2, dady = x / r2;
+					const double dDxxDx = 2. * (DPar - DPerp) * sa * ca * dadx;
+					const double dDyyDy = 2. * (DPerp - DPar) * sa * ca * dady;
+					const double dDxyDx = (DPerp - DPar) * (sqr(ca) - sqr(sa)) * dadx;
+					const double dDxyDy = (DPerp - DPar) * (sqr(ca) - sqr(sa)) * dady;
+					rhs(ix, iy, iz) = (dDyyDy + dDxyDx) * pi * sx * cy * sz + (dDxxDx + dDxyDy) * pi * cx * sy * sz +
+					                  2. * dxy * sqr(pi) * cx * cy * sz - ((dxx + dyy + dzz) * sqr(pi) + lam) * ana;
+					break;
+				}
+				default:  // test 5: unit tensor fields through the field interface (main.C:313-336)
+					if (ix == m || iy == m || iz == m) phi_ana(ix, iy, iz) = 0.;
+					D[0](ix, iy, iz) = dfac[0]; D[1](ix, iy, iz) = dfac[1]; D[2](ix, iy, iz) = dfac[2]; D[3](ix, iy, iz) = 0.;
+					rhs(ix, iy, iz) = -(sqr(pi) * (1. + 1. + 1.) + lam) * phi_ana(ix, iy, iz);
+					break;
+				}
+			}
+
+	if (!opt.stats) cout << " bauen " << endl;
+	Linsolver3D *lin_solver = new BICGStab();
+	NumArray<int> pars(1);
+	pars(0) = opt.L;
+	lin_solver->setup(grid_x, grid_y, grid_z, opt.tol, pars, false, false, opt.max_iter);
+
+	if (!opt.stats) cout << " lösen " << endl;
+	const int dbg = (opt.quiet || opt.stats) ? 0 : 8;
+	const auto t0 = chrono::steady_clock::now();
+	if (opt.test == 1) lin_solver->solve(MyBounds, phi, rhs, lambda, Diff[0], Diff[1], Diff[2], dbg);
+	else if (opt.test == 2 || opt.test == 5) lin_solver->solve(MyBounds, phi, rhs, lambda, D[0], D[1], D[2], D[3], dbg);
+	else lin_solver->solve(MyBounds, phi, rhs, lambda, D[0], D[1], D[2], D[3], dbg, true);
+	const double runtime = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
+	if (!opt.stats) cout << "Solver fertig in " << (long long)runtime << " ms" << endl;
+
+	// l2 and max error against the analytic solution (main.C:503-567)
+	double error = 0., num = 0., emax = 0.;
+	for (int iz = 0; iz <= m; ++iz)
+		for (int iy = 0; iy <= m; ++iy)
+			for (int ix = 0; ix <= m; ++ix) {
+				const double d = phi_ana(ix, iy, iz) - phi(ix, iy, iz);
+				error += sqr(d);
+				num += 1.;
+				emax = max(emax, fabs(d));
+			}
+	const double l2err = sqrt(error / num);
+
+	BICGStab *bs = static_cast<BICGStab *>(lin_solver);
+	if (opt.stats) {
+		// columns of the reference's --stats row (BiCGStab3D_CL/main.cpp:576,600-602)
+		const int it = bs->iterations();
+		const double calc = bs->solveRuntime();
+		const double avg = it > 0 ? calc / it : 0.;
+		cout << "# Test, Size, Iterations, Total runtime, Calculation time, Min step time, Max step time, "
+		        "Average (arithmetic), Average (geometric), Tolerance, L2 error, Max error" << endl;
+		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, m, it, runtime, calc, avg, avg,
+		       avg, avg, opt.tol, l2err, emax);
+	} else {
+		cout << " l2 error for " << m << " is " << l2err << endl;
+		cout << "Runtime (solver) : " << (long long)runtime << " ms" << endl;
+		cout << "Iterations       : " << bs->iterations() << " (" << bs->solveRuntime() << " ms on the device, "
+		     << (bs->usedFusedKernels() ? "fused" : "generic") << " kernels)" << endl;
+	}
+	delete lin_solver;
+	return EXIT_SUCCESS;
+}
