@@ -1,0 +1,63 @@
+"""Full-size checks at 256^3 (the single-GPU size of the benchmark configs),
+where the CPU oracle would take minutes: size-independent properties only."""
+import numpy as np
+import pytest
+
+from helpers import points, rel_l2
+from krylov_amd import capi, problems as P
+
+pytestmark = pytest.mark.gpu
+
+N = 256
+
+
+@pytest.fixture(scope="module")
+def prob():
+    p = P.smooth_var(N)
+    p.rhs = np.random.default_rng(1).uniform(-1, 1, p.rhs.shape)
+    return p
+
+
+def test_fused_and_generic_operator_agree_bit_for_bit(prob):
+    p = prob
+    psi = np.random.default_rng(2).uniform(-1, 1, p.rhs.shape)
+    with capi.Solver(p.mx, p.delx, p.bc) as s:
+        a = s.op_spmv_var(psi, p.lam, p.Dxx, p.Dyy, p.Dzz, None, False, fused=True)
+        b = s.op_spmv_var(psi, p.lam, p.Dxx, p.Dyy, p.Dzz, None, False, fused=False)
+    assert np.array_equal(points(a), points(b))
+    assert np.all(np.isfinite(a)) and np.abs(points(a)).max() > 0
+
+
+def test_operator_linearity(prob):
+    p = prob
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(-1, 1, p.rhs.shape), rng.uniform(-1, 1, p.rhs.shape)
+    with capi.Solver(p.mx, p.delx, p.bc) as s:
+        f = lambda v: s.op_spmv_var(v, p.lam, p.Dxx, p.Dyy, p.Dzz, None, False, fused=True)
+        lhs, rhs = f(x + 2.0 * y), f(x) + 2.0 * f(y)
+    assert np.max(np.abs(lhs - rhs)) <= 1e-10 * np.max(np.abs(rhs))
+
+
+def test_slabs_agree_with_single_slab_at_full_size(prob):
+    one = capi.solve_problem(prob, L=2, eps=1e-30, max_outer=3)
+    four = capi.solve_problem(prob, L=2, eps=1e-30, max_outer=3, nslabs_local=4, devices=(0,))
+    assert one["fused"] and four["fused"]
+    assert np.max(np.abs(one["history"] - four["history"])) <= 1e-11 * one["norm_rhs"]
+    assert rel_l2(points(four["phi"]), points(one["phi"])) <= 1e-11
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_converged_solution_has_small_true_residual(prob, L):
+    p = prob
+    got = capi.solve_problem(p, L=L, eps=1e-6)
+    assert got["status"] == 0 and got["fused"]
+    assert got["history"][-1] <= 1e-6 * got["norm_rhs"]
+    # residual recomputed with the generic (non-fused) operator kernel
+    with capi.Solver(p.mx, p.delx, p.bc) as s:
+        ax = s.op_spmv_var(got["phi"], p.lam, p.Dxx, p.Dyy, p.Dzz, None, False, apply_bcs=False, fused=False)
+        r = P.interior_only(p.rhs - ax)
+        r[1, :, :] = r[-2, :, :] = 0
+        r[:, 1, :] = r[:, -2, :] = 0
+        r[:, :, 1] = r[:, :, -2] = 0
+        nrm = s.op_l2norm(r)
+    assert nrm <= 2e-6 * got["norm_rhs"]
