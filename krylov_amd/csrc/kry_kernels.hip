@@ -19,6 +19,7 @@
 #define NT 256                 // threads per block in every kernel here
 #define NW (NT / 64)           // wavefronts per block
 #define TXW KRY_TXW            // tile width in grid points = one 1 KiB wave load of double2
+#define QOFF 2                  // streaming kernels start a plane at column 2: 128-byte aligned wave loads
 #define SEG2 1024               // double2 elements of a plane segment handled per block and plane
 #define LW 132                 // LDS row pitch: col 1 = left halo, 2..129 = tile, 130 = right halo
 
@@ -214,6 +215,25 @@ __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r)
 // ---------------------------------------------------------------------------
 __device__ inline double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 __device__ inline void st2(double *p, double2 v) { *reinterpret_cast<double2 *>(p) = v; }
+// Streaming (non-temporal) forms for data that is touched once per kernel: they
+// keep the one-pass streams from evicting the lines neighbouring tiles re-read.
+typedef double kry_d2 __attribute__((ext_vector_type(2)));
+__device__ inline double2 ld2s(const double *p)
+{
+	kry_d2 v = __builtin_nontemporal_load(reinterpret_cast<const kry_d2 *>(p));
+	double2 r;
+	r.x = v.x;
+	r.y = v.y;
+	return r;
+}
+__device__ inline void st2s(double *p, double2 v)
+{
+	kry_d2 w;
+	w.x = v.x;
+	w.y = v.y;
+	__builtin_nontemporal_store(w, reinterpret_cast<kry_d2 *>(p));
+}
+__device__ inline void st1s(double *p, double v) { __builtin_nontemporal_store(v, p); }
 __device__ inline double2 axpy2(double2 x, double2 y, double c)
 {
 	// x + (y*c): product rounded, then sum rounded (solveLin_BICGStab.C:358-360, 393)
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			if (mrow[e]) {
-				if (mxx && mxy) st2(a.Xout + pb + off[e], v[e]);
+				if (mxx && mxy) st2s(a.Xout + pb + off[e], v[e]);
 				else if (mxx) a.Xout[pb + off[e]] = v[e].x;
 				else if (mxy) a.Xout[pb + off[e] + 1] = v[e].y;
 			}
@@ -412,21 +432,21 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		if (KIND == KF_A1) {
 			// phi += u0*alpha (solveLin_BICGStab.C:403, deferred from jj = 0), then
 			// u0 = r0 - beta*u0 (:356-362, ii = 0 of jj = 1)
-			double2 u0 = ld2(a.E + p), r0 = ld2(a.Ea + p), ph = ld2(a.phi + p);
+			double2 u0 = ld2s(a.E + p), r0 = ld2s(a.Ea + p), ph = ld2s(a.phi + p);
 			ph = axpy2(ph, u0, alpha_prev);
 			double2 un = axpy2(r0, u0, cpsi);
 			if (mrow[e]) {
-				if (mxx && mxy) { st2(a.phi + p, ph); st2(a.E + p, un); }
+				if (mxx && mxy) { st2s(a.phi + p, ph); st2s(a.E + p, un); }
 				else if (mxx) { a.phi[p] = ph.x; a.E[p] = un.x; }
 				else if (mxy) { a.phi[p + 1] = ph.y; a.E[p + 1] = un.y; }
 			}
 			comp = un;
 		} else if (KIND == KF_B1L) {
 			// r0 -= alpha*u1 (:392-394, ii = 0 of jj = 1)
-			double2 r0 = ld2(a.E + p), u1 = ld2(a.Ea + p);
+			double2 r0 = ld2s(a.E + p), u1 = ld2s(a.Ea + p);
 			double2 rn = axpy2(r0, u1, cpsi);
 			if (mrow[e]) {
-				if (mxx && mxy) st2(a.E + p, rn);
+				if (mxx && mxy) st2s(a.E + p, rn);
 				else if (mxx) a.E[p] = rn.x;
 				else if (mxy) a.E[p + 1] = rn.y;
 			}
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			const long p = pb + off[e];
 			const int li = lidx[e];
 			Sten s0, s1;
-			const double2 lam = ld2(a.lam + p);
+			const double2 lam = ld2s(a.lam + p);
 			const double xl = buf[li - 1], xr = buf[li + 2];
 			const double2 ym = ld2(buf + li - LW), yp = ld2(buf + li + LW);
 			s0.pc = pc[e].x; s1.pc = pc[e].y;
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			out.y = apply_op<VAR, OFFD, EXACT>(s1, a.op);
 			if (KIND == KF_RES) {
 				// residual = rhs - A*phi (Krylov.C:259, 325)
-				const double2 rh = ld2(a.RHS + p);
+				const double2 rh = ld2s(a.RHS + p);
 				out.x = rh.x - out.x;
 				out.y = rh.y - out.y;
 			}
@@ -523,8 +543,8 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			extras(z, e, comp);
 			const bool m0 = mrow[e] && mxx, m1 = mrow[e] && mxy;
 			if (m0 && m1) {
-				st2(a.O + p, out);
-				if (KIND == KF_RES) st2(a.O2 + p, out);
+				st2s(a.O + p, out);
+				if (KIND == KF_RES) st2s(a.O2 + p, out);
 			} else if (m0) {
 				a.O[p] = out.x;
 				if (KIND == KF_RES) a.O2[p] = out.x;
@@ -539,7 +559,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				s += c1 ? vy : 0.;
 			};
 			if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
-				const double2 rt = ld2(a.RT + p);
+				const double2 rt = ld2s(a.RT + p);
 				add(acc[0], out.x * rt.x, out.y * rt.y);
 			} else if (KIND == KF_B0L) {
 				add(acc[0], pc[e].x * out.x, pc[e].y * out.y);
@@ -584,23 +604,31 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 {
 	KryState *S = a.S;
 	if (S->done) return;
+	constexpr int UN = SEG2 / NT;
 	const double ntau = -S->tau[1][2];
 	double acc[2] = {0., 0.};
+	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
-		const long pb = (long)(z + 1) * a.g.ps;
+		const long pb = (long)(z + 1) * a.g.ps + QOFF;
+		// all loads first (reads past the end of a plane stay inside the allocation)
+		double2 r2[UN], r1[UN], r0[UN];
 #pragma unroll
-		for (int i = 0; i < SEG2 / NT; ++i) {
-			const long q = 2 * ((long)blockIdx.x * SEG2 + i * NT + threadIdx.x);
-			if (q >= a.g.ps) break;
-			const long p = pb + q;
-			double2 r2 = ld2(a.v[2] + p), r1 = ld2(a.v[1] + p), r0 = ld2(a.v[0] + p);
-			r2 = axpy2(r2, r1, ntau);
-			st2(a.w[0] + p, r2);
-			if (cnt) {
-				acc[0] += r2.x * r2.x; acc[0] += r2.y * r2.y;
-				acc[1] += r0.x * r2.x; acc[1] += r0.y * r2.y;
+		for (int i = 0; i < UN; ++i) {
+			const long p = pb + q0 + 2L * i * NT;
+			r2[i] = ld2s(a.v[2] + p); r1[i] = ld2s(a.v[1] + p); r0[i] = ld2s(a.v[0] + p);
+		}
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			const long q = q0 + 2L * i * NT;
+			if (q < a.g.ps) {
+				r2[i] = axpy2(r2[i], r1[i], ntau);
+				st2s(a.w[0] + pb + q, r2[i]);
+				if (cnt) {
+					acc[0] += r2[i].x * r2[i].x; acc[0] += r2[i].y * r2[i].y;
+					acc[1] += r0[i].x * r2[i].x; acc[1] += r0[i].y * r2[i].y;
+				}
 			}
 		}
 	}
@@ -622,37 +650,45 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 	double g1[L + 1], gp[L + 1], gpp[L + 1];
 #pragma unroll
 	for (int j = 1; j <= L; ++j) { g1[j] = S->gamma[j]; gp[j] = S->gammap[j]; gpp[j] = (j < L) ? S->gammapp[j] : 0.; }
+	constexpr int UN = SEG2 / NT;
 	double acc[2] = {0., 0.};
+	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
-		const long pb = (long)(z + 1) * a.g.ps;
+		const long pb = (long)(z + 1) * a.g.ps + QOFF;
+		double2 r[UN][L + 1], u[UN][L + 1], ph[UN], rt[UN];
+		// all loads first (reads past the end of a plane stay inside the allocation)
 #pragma unroll
-		for (int i = 0; i < SEG2 / NT; ++i) {
-			const long q = 2 * ((long)blockIdx.x * SEG2 + i * NT + threadIdx.x);
-			if (q >= a.g.ps) break;
-			const long p = pb + q;
-			double2 r[L + 1], u[L + 1];
+		for (int i = 0; i < UN; ++i) {
+			const long p = pb + q0 + 2L * i * NT;
 #pragma unroll
-			for (int j = 0; j <= L; ++j) { r[j] = ld2(a.v[j] + p); u[j] = ld2(a.v[L + 1 + j] + p); }
-			double2 ph = ld2(a.w[0] + p);
-			const double2 rt = ld2(a.v[2 * L + 2] + p);
-			ph = axpy2(ph, u[0], alpha);
-			ph = axpy2(ph, r[0], g1[1]);
-			r[0] = axpy2(r[0], r[L], -gp[L]);
-			u[0] = axpy2(u[0], u[L], -g1[L]);
+			for (int j = 0; j <= L; ++j) { r[i][j] = ld2s(a.v[j] + p); u[i][j] = ld2s(a.v[L + 1 + j] + p); }
+			ph[i] = ld2s(a.w[0] + p);
+			rt[i] = ld2s(a.v[2 * L + 2] + p);
+		}
 #pragma unroll
-			for (int j = 1; j < L; ++j) {
-				u[0] = axpy2(u[0], u[j], -g1[j]);
-				ph = axpy2(ph, r[j], gpp[j]);
-				r[0] = axpy2(r[0], r[j], -gp[j]);
-			}
-			st2(a.w[0] + p, ph);
-			st2(a.w[1] + p, r[0]);
-			st2(a.w[2] + p, u[0]);
-			if (cnt) {
-				acc[0] += r[0].x * r[0].x; acc[0] += r[0].y * r[0].y;
-				acc[1] += r[0].x * rt.x;   acc[1] += r[0].y * rt.y;
+		for (int i = 0; i < UN; ++i) {
+			const long q = q0 + 2L * i * NT;
+			if (q < a.g.ps) {
+				const long p = pb + q;
+				double2 phv = axpy2(ph[i], u[i][0], alpha);
+				phv = axpy2(phv, r[i][0], g1[1]);
+				double2 r0 = axpy2(r[i][0], r[i][L], -gp[L]);
+				double2 u0 = axpy2(u[i][0], u[i][L], -g1[L]);
+#pragma unroll
+				for (int j = 1; j < L; ++j) {
+					u0 = axpy2(u0, u[i][j], -g1[j]);
+					phv = axpy2(phv, r[i][j], gpp[j]);
+					r0 = axpy2(r0, r[i][j], -gp[j]);
+				}
+				st2s(a.w[0] + p, phv);
+				st2s(a.w[1] + p, r0);
+				st2s(a.w[2] + p, u0);
+				if (cnt) {
+					acc[0] += r0.x * r0.x;   acc[0] += r0.y * r0.y;
+					acc[1] += r0.x * rt[i].x; acc[1] += r0.y * rt[i].y;
+				}
 			}
 		}
 	}

@@ -97,7 +97,8 @@ struct kry_solver {
 	bool loaded = false;
 	KryOp op;
 	int ty = 8, zc = 16;
-	int stream_blocks = 2048;  // target grid size of the streaming kernels
+	bool zc_fixed = false;     // KRY_ZC given: no automatic choice
+	int stream_blocks = 32768; // target grid size of the streaming kernels
 	std::vector<Slab> slabs;
 	KryComm comm;
 	// run state
@@ -975,7 +976,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	h->L = d->L;
 	h->mzl = d->mx[2] / d->slab_count;
 	if (const char *e = getenv("KRY_TY")) h->ty = (atoi(e) == 8) ? 8 : 16;
-	if (const char *e = getenv("KRY_ZC")) h->zc = std::max(1, atoi(e));
+	if (const char *e = getenv("KRY_ZC")) { h->zc = std::max(1, atoi(e)); h->zc_fixed = true; }
 	if (const char *e = getenv("KRY_STREAM_BLOCKS")) h->stream_blocks = std::max(64, atoi(e));
 	if (const char *e = getenv("KRY_PROFILE")) h->profile = atoi(e) != 0;
 	h->slabs.resize(d->slab_count);
@@ -1037,6 +1038,14 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		return 0;
 	};
 	st = build();
+	if (st >= 0 && !h->zc_fixed) {
+		// planes per fused chunk: long chunks re-read fewer halo planes, but the grid
+		// should still hold about a thousand blocks
+		const KryGeo &g = h->slabs[0].g;
+		const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + h->ty - 1) / h->ty);
+		const int chunks = std::max(1, (1024 + tiles - 1) / tiles);
+		h->zc = std::min(64, std::max(8, (g.mz + chunks - 1) / chunks));
+	}
 	if (st < 0) {
 		kry_destroy(h);
 		return fail(st);

@@ -129,9 +129,9 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B)
 						const long q = 2 * ((long)bx * 1024 + i * NT + t);
 						if (q >= ps) break;
 						for (int d = 0; d < 2; ++d) {
-							const long qq = q + d;
+							const long qq = q + d + 2;   /* the kernels start a plane at column 2 */
 							const int jj = (int)(qq / px) - 1, ii = (int)(qq % px) - 2;
-							if (ii >= 1 && ii <= b.mx - 1 && jj >= 1 && jj <= b.my - 1)
+							if (ii >= 1 && ii <= b.mx - 1 && jj >= 1 && jj <= b.my - 1 && qq < ps)
 								s += HAT(b, A, ii, jj, z) * HAT(b, B, ii, jj, z);
 						}
 					}
