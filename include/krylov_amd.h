@@ -97,6 +97,21 @@ void       kry_destroy(kry_handle h);
 int kry_comm_unique_id(void *uid /* KRY_UID_BYTES */);
 int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks);
 
+/* The same role with the caller's own transport instead of RCCL, e.g. the
+ * MPI communicator of a `-D parallel` build (the reference exchanges faces with
+ * MPI_Isend/MPI_Irecv, BICGStab3D/BoundaryHandler.C:1633-1677, and reduces with
+ * MPI_Allreduce, BICGStab3D/Krylov.C:239-240).  Both callbacks get DEVICE
+ * pointers, are called with the slab's stream idle, must complete before they
+ * return and return 0 on success.
+ *   allreduce: in-place sum of n doubles over all ranks;
+ *   halo:      send `count` doubles to / receive `count` doubles from the lower
+ *              and upper z neighbour (a peer < 0 means no neighbour). */
+typedef int (*kry_allreduce_cb)(void *ctx, double *device_buf, int n);
+typedef int (*kry_halo_cb)(void *ctx, int peer_lo, const double *send_lo, double *recv_lo, int peer_hi,
+                           const double *send_hi, double *recv_hi, unsigned long count);
+int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
+                            void *ctx);
+
 /* Replaces BICGStab::solve(bounds, phi, rhs, lambda, D_xx, D_yy, D_zz, debug)
  * (BICGStab3D/solveLin_BICGStab.C:200-215).  phi: initial guess in, solution
  * out.  Returns a status instead of calling exit(). */

@@ -21,7 +21,8 @@ STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reache
 
 # every symbol include/krylov_amd.h declares
 SYMBOLS = [
-    "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_solve_const",
+    "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks",
+    "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
     "kry_get_stats", "kry_get_history", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
@@ -63,6 +64,11 @@ class KryStats(C.Structure):
     ]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+HALO_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                      C.c_ulong)
+
+
 class KryError(RuntimeError):
     pass
 
@@ -89,6 +95,8 @@ def lib():
     L.kry_comm_unique_id.argtypes = [vp]
     L.kry_comm_init.restype = ci
     L.kry_comm_init.argtypes = [vp, vp, ci, ci]
+    L.kry_comm_init_callbacks.restype = ci
+    L.kry_comm_init_callbacks.argtypes = [vp, ci, ci, ALLREDUCE_CB, HALO_CB, vp]
     L.kry_solve_const.restype = ci
     L.kry_solve_const.argtypes = [vp, _dp, _dp, _dp, cd, cd, cd, ci]
     L.kry_solve_var.restype = ci
@@ -184,6 +192,30 @@ class Solver:
     def comm_init(self, uid, rank, nranks):
         buf = C.create_string_buffer(bytes(uid), KRY_UID_BYTES)
         _check(lib().kry_comm_init(self._h, buf, rank, nranks), "kry_comm_init")
+
+    def comm_init_callbacks(self, rank, nranks, allreduce, halo):
+        """allreduce(dev_ptr, n) and halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, count)
+        are Python callables taking device addresses (ints); they return nothing."""
+        def ar(ctx, buf, n):
+            try:
+                allreduce(buf, n)
+                return 0
+            except Exception:          # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def hl(ctx, plo, slo, rlo, phi_, shi, rhi, count):
+            try:
+                halo(plo, slo, rlo, phi_, shi, rhi, count)
+                return 0
+            except Exception:          # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cbs = (ALLREDUCE_CB(ar), HALO_CB(hl))      # keep alive
+        _check(lib().kry_comm_init_callbacks(self._h, rank, nranks, self._cbs[0], self._cbs[1], None),
+               "kry_comm_init_callbacks")
 
     def solve_const(self, phi, rhs, lam, Dc, debug=0):
         return _check(lib().kry_solve_const(self._h, phi, rhs, lam, Dc[0], Dc[1], Dc[2], debug),

@@ -95,14 +95,32 @@ int KryComm::init(const void *uid, int rank, int nranks)
 	return 0;
 }
 
+int KryComm::init_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx)
+{
+	if (!ar || !hl) { g_cerr = "null callback"; return -1; }
+	cb_allreduce_ = ar;
+	cb_halo_ = hl;
+	cb_ctx_ = ctx;
+	rank_ = rank;
+	nranks_ = nranks;
+	return 0;
+}
+
 void KryComm::destroy()
 {
+	cb_allreduce_ = nullptr;
+	cb_halo_ = nullptr;
 	if (comm_ && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(comm_));
 	comm_ = nullptr;
 }
 
 int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
 {
+	if (cb_allreduce_) {
+		if (hipStreamSynchronize(st) != hipSuccess) { g_cerr = "stream synchronize failed"; return -2; }
+		if (cb_allreduce_(cb_ctx_, buf, n) != 0) { g_cerr = "allreduce callback failed"; return -3; }
+		return 0;
+	}
 	NCHK(g_api.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, static_cast<ncclComm_t>(comm_), st));
 	return 0;
 }
@@ -111,6 +129,14 @@ int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_
                   double *recv_hi, size_t count, hipStream_t st)
 {
 	if (peer_lo < 0 && peer_hi < 0) return 0;
+	if (cb_halo_) {
+		if (hipStreamSynchronize(st) != hipSuccess) { g_cerr = "stream synchronize failed"; return -2; }
+		if (cb_halo_(cb_ctx_, peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (unsigned long)count) != 0) {
+			g_cerr = "halo callback failed";
+			return -3;
+		}
+		return 0;
+	}
 	ncclComm_t c = static_cast<ncclComm_t>(comm_);
 	NCHK(g_api.GroupStart());
 	if (peer_lo >= 0) {

@@ -13,8 +13,12 @@ public:
 	static const char *last_error();
 
 	int init(const void *uid, int rank, int nranks);
+	// caller-provided transport (device pointers, blocking); see include/krylov_amd.h
+	typedef int (*allreduce_fn)(void *, double *, int);
+	typedef int (*halo_fn)(void *, int, const double *, double *, int, const double *, double *, unsigned long);
+	int init_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx);
 	void destroy();
-	bool active() const { return comm_ != nullptr; }
+	bool active() const { return comm_ != nullptr || cb_allreduce_ != nullptr; }
 	int rank() const { return rank_; }
 	int nranks() const { return nranks_; }
 
@@ -27,5 +31,8 @@ public:
 
 private:
 	void *comm_ = nullptr;
+	allreduce_fn cb_allreduce_ = nullptr;
+	halo_fn cb_halo_ = nullptr;
+	void *cb_ctx_ = nullptr;
 	int rank_ = 0, nranks_ = 1;
 };

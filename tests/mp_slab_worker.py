@@ -1,0 +1,94 @@
+"""Worker of tests/test_gpu_multiproc.py: one process = one z slab, all
+processes share GPU 0.  The inter-process transport is the callback form of
+the C ABI, implemented with device<->host copies and torch.distributed (gloo);
+everything else is the library's own multi-process code path (the same one the
+RCCL transport drives on a multi-GPU node).
+
+usage: mp_slab_worker.py RANK WORLD PORT KIND L MAX_OUTER EPS OUTDIR
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    kind, L, max_outer, eps, outdir = sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7]), sys.argv[8]
+
+    # the solver library (and with it the ROCm HIP runtime) before torch
+    from krylov_amd import capi, problems as P
+    capi.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    D2H, H2D = 2, 1
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def to_host(dev, n):
+        t = torch.empty(n, dtype=torch.float64)
+        assert hip.hipMemcpy(t.data_ptr(), dev, n * 8, D2H) == 0
+        return t
+
+    def to_dev(dev, t):
+        assert hip.hipMemcpy(dev, t.data_ptr(), t.numel() * 8, H2D) == 0
+
+    def allreduce(buf, n):
+        t = to_host(buf, n)
+        # sum in rank order on every rank: gather, then add
+        parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, t)
+        acc = parts[0].clone()
+        for q in parts[1:]:
+            acc += q
+        to_dev(buf, acc)
+
+    def halo(plo, slo, rlo, phi_, shi, rhi, count):
+        reqs, got = [], []
+        if plo >= 0:
+            s, r = to_host(slo, count), torch.empty(count, dtype=torch.float64)
+            reqs += [dist.isend(s, plo), dist.irecv(r, plo)]
+            got.append((rlo, r))
+        if phi_ >= 0:
+            s, r = to_host(shi, count), torch.empty(count, dtype=torch.float64)
+            reqs += [dist.isend(s, phi_), dist.irecv(r, phi_)]
+            got.append((rhi, r))
+        for q in reqs:
+            q.wait()
+        for dev, r in got:
+            to_dev(dev, r)
+
+    import slab_reference as SR
+    from test_gpu_multiproc import make_problem
+    p = make_problem(kind)
+    loc = SR.split_problem(P, p, world, rank)
+    flags = capi.KRY_FORCE_GENERIC if kind == "mixed" else 0
+    with capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs=world,
+                     slab_begin=rank, slab_count=1, devices=(0,)) as s:
+        s.comm_init_callbacks(rank, world, allreduce, halo)
+        phi = loc.phi.copy()
+        if loc.var_coef:
+            st = s.solve_var(phi, loc.rhs, loc.lam, loc.Dxx, loc.Dyy, loc.Dzz, loc.Dxy, loc.use_offdiag)
+        else:
+            st = s.solve_const(phi, loc.rhs, loc.lam, loc.Dc)
+        stats = s.stats()
+        hist = s.history()
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), phi=phi, hist=hist, status=st, iters=stats.iterations,
+             fused=stats.fused, norm_rhs=stats.norm_rhs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

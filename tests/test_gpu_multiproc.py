@@ -1,0 +1,90 @@
+"""One process per z slab (the layout of `bench.py --gpus N`), all on GPU 0,
+with a host-staged gloo transport plugged into the C ABI's callback hooks.
+Checks the library's multi-process orchestration -- per-process scalar state
+advanced after an inter-process all-reduce, operator outputs exchanged between
+processes -- against the single-process solve."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from krylov_amd import problems as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+gpu = pytest.mark.gpu
+
+
+def make_problem(kind):
+    rng = np.random.default_rng(23)
+    if kind == "const":
+        p = P.reference_test1(32)
+        p.rhs = P.interior_only(rng.uniform(-1, 1, p.rhs.shape))
+    elif kind == "var":
+        p = P.smooth_var(32)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    elif kind == "mixed":
+        p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    else:
+        raise KeyError(kind)
+    return p
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_ranks(world, kind, L, max_outer, eps, outdir):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_slab_worker.py"), str(r), str(world), str(port),
+                               kind, str(L), str(max_outer), repr(eps), outdir]) for r in range(world)]
+    try:
+        codes = [q.wait(timeout=240) for q in procs]
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    assert codes == [0] * world
+    return [np.load(os.path.join(outdir, "r%d.npz" % r)) for r in range(world)]
+
+
+@gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2)])
+def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
+    from helpers import points, rel_l2
+    from krylov_amd import capi
+    p = make_problem(kind)
+    flags = capi.KRY_FORCE_GENERIC if kind == "mixed" else 0
+    one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, flags=flags)
+    parts = run_ranks(world, kind, L, 3, 1e-30, str(tmp_path))
+    mzl = p.mx[2] // world
+    for r, d in enumerate(parts):
+        assert int(d["iters"]) == 3 and bool(d["fused"]) == one["fused"]
+        assert float(d["norm_rhs"]) == pytest.approx(one["norm_rhs"], rel=1e-13)
+        assert np.max(np.abs(d["hist"] - one["history"])) <= 1e-10 * one["norm_rhs"]
+        mine = d["phi"][1:mzl + 2, 1:-1, 1:-1]
+        ref = one["phi"][r * mzl + 1: r * mzl + mzl + 2, 1:-1, 1:-1]
+        assert np.max(np.abs(mine - ref)) <= 1e-10 * np.max(np.abs(ref))
+    # every rank holds the same history, bit for bit
+    for d in parts[1:]:
+        assert np.array_equal(d["hist"], parts[0]["hist"])
+
+
+@gpu
+def test_processes_full_solve(tmp_path):
+    from krylov_amd import capi
+    p = make_problem("var")
+    one = capi.solve_problem(p, L=2, eps=1e-6)
+    parts = run_ranks(2, "var", 2, 0, 1e-6, str(tmp_path))
+    for d in parts:
+        assert int(d["status"]) == 0
+        assert d["hist"][-1] <= 1e-6 * one["norm_rhs"]
+        assert abs(int(d["iters"]) - one["iters"]) <= max(8, one["iters"] // 3)
