@@ -41,7 +41,11 @@ struct KryFused {
 	KryRed red;
 	int zlo, zhi;            // planes on which the stencil is evaluated
 	int zc;                  // planes per chunk
-	int ntx, nty, nchunk, nblk;
+	int ntx, nty, nchunk;
+	int nblk;                // blocks of THIS launch
+	int ch_sel;              // 0: all chunks, 1: chunk 0 and the last n_edge-1 chunks, 2: the chunks in between
+	int n_edge;              // 2 or 3
+	int blk_off;             // offset of this launch's blocks in the partial-sum array
 };
 
 #define KRY_STREAM_MAXV (2 * KRY_LMAX + 3)

@@ -155,9 +155,9 @@ __device__ inline double pub_load(const double *p)
 }
 
 template <int ND>
-__device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r)
+__device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, int blk_off = 0)
 {
-	const long bid = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+	const long bid = blk_off + blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
 	__shared__ double red[NW][ND];
 	__shared__ int is_last;
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -339,7 +339,11 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	}
 	const int tx = bid % a.ntx;
 	const int ty = (bid / a.ntx) % a.nty;
-	const int ch = bid / (a.ntx * a.nty);
+	int ch = bid / (a.ntx * a.nty);
+	// a launch covers all chunks, the outermost ones (chunk 0 and the last n_edge-1
+	// chunks: those holding the planes the neighbours need), or the ones in between
+	if (a.ch_sel == 1) ch = ch ? a.nchunk - a.n_edge + ch : 0;
+	else if (a.ch_sel == 2) ch += 1;
 
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int z0 = a.zlo + ch * a.zc;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 
 	if (KIND != KF_SPMV) {
 		KryRed r = a.red;
-		reduce_and_finalize<ND>(acc, r);
+		reduce_and_finalize<ND>(acc, r, a.blk_off);
 	}
 }
 

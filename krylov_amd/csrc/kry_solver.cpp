@@ -65,8 +65,11 @@ struct Slab {
 	int index = 0;             // global slab index
 	int device = 0;
 	hipStream_t st = nullptr;
+	hipStream_t st_comm = nullptr;   // halo traffic, overlapped with the interior chunks
 	hipEvent_t ev = nullptr;   // "this slab's last kernel of the phase is queued"
 	hipEvent_t ev_in = nullptr;
+	hipEvent_t ev_edge = nullptr;    // the outermost chunks of a stencil kernel are done
+	hipEvent_t ev_halo = nullptr;    // this slab's ghost planes are filled
 	KryGeo g;
 	long guard = 0;
 	Field phi, rhs, lam, Dxx, Dyy, Dzz, Dxy, rt, tmp;
@@ -109,6 +112,7 @@ struct kry_solver {
 	double solve_ms = 0, stage_ms = 0;
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
 	bool profile = false;
+	bool overlap = true;       // halo exchange concurrent with the interior chunks
 	Prof prof;
 	double kernel_ms[8] = {0};
 	int kernel_calls[8] = {0};
@@ -303,8 +307,57 @@ int exchange_halo(kry_solver *h, std::vector<double *> &f)
 	return 0;
 }
 
-// A halo exchange orders the streams of neighbouring local slabs; after a
-// pointwise-only kernel nothing needs to move, so nothing is exchanged.
+// The same exchange on the slabs' communication streams: it starts when the
+// outermost chunks of the producing kernel are done (ev_edge) and overlaps with
+// the chunks in between, which the caller queues on the main streams next.
+// Every main stream then waits for its ghost planes (ev_halo).
+int exchange_halo_begin(kry_solver *h, std::vector<double *> &f)
+{
+	const int ns = (int)h->slabs.size();
+	const size_t bytes = (size_t)h->slabs[0].g.ps * sizeof(double);
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipEventRecord(s.ev_edge, s.st));
+	}
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		const KryGeo &g = s.g;
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipStreamWaitEvent(s.st_comm, s.ev_edge, 0));
+		if (i > 0) {         // ghost -1 <- lower slab's plane mz-1
+			HIPCHK(hipStreamWaitEvent(s.st_comm, h->slabs[i - 1].ev_edge, 0));
+			HIPCHK(hipMemcpyAsync(f[i], f[i - 1] + (long)g.mz * g.ps, bytes, hipMemcpyDeviceToDevice, s.st_comm));
+		}
+		if (i + 1 < ns) {    // ghost mz+1 <- upper slab's plane 1
+			HIPCHK(hipStreamWaitEvent(s.st_comm, h->slabs[i + 1].ev_edge, 0));
+			HIPCHK(hipMemcpyAsync(f[i] + (long)(g.mz + 2) * g.ps, f[i + 1] + 2L * g.ps, bytes, hipMemcpyDeviceToDevice,
+			                      s.st_comm));
+		}
+		if (h->comm.active()) {
+			double *b = f[i];
+			CHK(h->comm.halo(g.has_lo ? s.index - 1 : -1, b + 2L * g.ps, b, g.has_hi ? s.index + 1 : -1,
+			                 b + (long)g.mz * g.ps, b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st_comm));
+		}
+		HIPCHK(hipEventRecord(s.ev_halo, s.st_comm));
+	}
+	return 0;
+}
+
+int exchange_halo_end(kry_solver *h)
+{
+	// a slab may go on once its own ghosts are filled AND its neighbours have
+	// read the planes they copy from it (later kernels update those in place)
+	const int ns = (int)h->slabs.size();
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipStreamWaitEvent(s.st, s.ev_halo, 0));
+		if (i > 0) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i - 1].ev_halo, 0));
+		if (i + 1 < ns) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i + 1].ev_halo, 0));
+	}
+	return 0;
+}
 
 KryRed make_red(Slab &s, int nblk, int phase)
 {
@@ -351,16 +404,19 @@ KryFused fused_base(kry_solver *h, Slab &s, int phase)
 	a.phi = s.phi.p;
 	a.zlo = t.zlo; a.zhi = t.zhi; a.zc = h->zc;
 	a.ntx = t.ntx; a.nty = t.nty; a.nchunk = t.nchunk; a.nblk = t.nblk;
+	a.ch_sel = 0;
+	a.blk_off = 0;
 	a.red = make_red(s, t.nblk, phase);
 	return a;
 }
 
-int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a)
+// prof: 1 = open the timing bracket before the launch, 2 = close it after, 3 = both
+int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof = 3)
 {
 	HIPCHK(hipSetDevice(s.device));
-	prof_begin(h, s, kind);
+	if (prof & 1) prof_begin(h, s, kind);
 	HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
-	prof_end(h, s);
+	if (prof & 2) prof_end(h, s);
 	return 0;
 }
 
@@ -384,71 +440,113 @@ KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby)
 	return a;
 }
 
+// Launch one fused stencil kernel on every slab and fill the neighbours' ghost
+// planes of its output.  With several slabs the two outermost chunks go first,
+// the exchange runs on the communication streams, and the chunks in between are
+// computed meanwhile.
+template <class MakeArgs>
+int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
+{
+	const int ns = (int)h->slabs.size();
+	const bool multi = ns > 1 || h->comm.active();
+	std::vector<KryFused> args(ns);
+	std::vector<double *> outs(ns);
+	for (int i = 0; i < ns; ++i) {
+		args[i] = make_args(h->slabs[i]);
+		outs[i] = args[i].O;
+	}
+	// the neighbours need planes 1 and mz-1: chunk 0 and the chunk holding plane mz-1
+	// (the last one, or the one before it when the last chunk is plane mz alone)
+	std::vector<int> n_edge(ns);
+	bool split = multi && h->overlap;
+	for (int i = 0; i < ns; ++i) {
+		const KryFused &a = args[i];
+		const int c_hi = (a.g.mz - 1 - a.zlo) / a.zc;
+		n_edge[i] = (c_hi == a.nchunk - 1) ? 2 : 3;
+		split = split && a.nchunk > n_edge[i];
+	}
+	if (!split) {
+		for (int i = 0; i < ns; ++i) CHK(launch_fused(h, h->slabs[i], kind, args[i]));
+		if (multi) CHK(exchange_halo(h, outs));
+		return 0;
+	}
+	for (int i = 0; i < ns; ++i) {
+		KryFused a = args[i];
+		const int tiles = a.ntx * a.nty;
+		a.ch_sel = 1;
+		a.n_edge = n_edge[i];
+		a.nblk = n_edge[i] * tiles;
+		a.blk_off = 0;
+		CHK(launch_fused(h, h->slabs[i], kind, a, 1));
+	}
+	CHK(exchange_halo_begin(h, outs));
+	for (int i = 0; i < ns; ++i) {
+		KryFused a = args[i];
+		const int tiles = a.ntx * a.nty;
+		a.ch_sel = 2;
+		a.n_edge = n_edge[i];
+		a.nblk = (a.nchunk - n_edge[i]) * tiles;
+		a.blk_off = n_edge[i] * tiles;
+		CHK(launch_fused(h, h->slabs[i], kind, a, 2));
+	}
+	CHK(exchange_halo_end(h));
+	return 0;
+}
+
 // one outer pass, solveLin_BICGStab.C:327-496, as fused kernels
 int fused_pass(kry_solver *h, int it)
 {
 	const int p = it & 1, q = 1 - p;
 	const int L = h->L;
-	std::vector<double *> outs(h->slabs.size());
 	auto for_slabs = [&](auto &&fn) -> int {
 		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
 		return 0;
 	};
 
 	// --- jj = 0, A: u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
-	CHK(for_slabs([&](Slab &s, int i) -> int {
+	CHK(stencil_step(h, KF_A0, [&](Slab &s) {
 		KryFused a = fused_base(h, s, PH_A);
 		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
 		a.O = (L == 1 ? s.ub[1][0].p : s.ub[1][p].p);
-		outs[i] = a.O;
-		return launch_fused(h, s, KF_A0, a);
+		return a;
 	}));
-	CHK(exchange_halo(h, outs));
 	CHK(reduce_sums(h, PH_A));
 
 	if (L == 1) {
 		// --- B (last): r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
-		CHK(for_slabs([&](Slab &s, int i) -> int {
+		CHK(stencil_step(h, KF_B0L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL1);
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][0].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][0].p;
-			outs[i] = a.O;
-			return launch_fused(h, s, KF_B0L, a);
+			return a;
 		}));
-		CHK(exchange_halo(h, outs));
 		CHK(reduce_sums(h, PH_BL1));
 	} else {
 		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
-		CHK(for_slabs([&](Slab &s, int i) -> int {
+		CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_B);
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][p].p;
-			outs[i] = a.O;
-			return launch_fused(h, s, KF_B0, a);
+			return a;
 		}));
-		CHK(exchange_halo(h, outs));
 		CHK(reduce_sums(h, PH_B));
 		// --- jj = 1, A: phi += alpha*u0 ; u0 = r0 - beta*u0 ; u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
-		CHK(for_slabs([&](Slab &s, int i) -> int {
+		CHK(stencil_step(h, KF_A1, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_A);
 			a.X = s.rb[1][p].p; a.Y = s.ub[1][p].p; a.Xout = s.ub[1][q].p;
 			a.O = s.ub[2][0].p;
 			a.E = s.ub[0][q].p; a.Ea = s.rb[0][q].p;
-			outs[i] = a.O;
-			return launch_fused(h, s, KF_A1, a);
+			return a;
 		}));
-		CHK(exchange_halo(h, outs));
 		CHK(reduce_sums(h, PH_A));
 		// --- jj = 1, B (last): r0 -= alpha*u1 ; r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0,r1), (r2,r1)
-		CHK(for_slabs([&](Slab &s, int i) -> int {
+		CHK(stencil_step(h, KF_B1L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL2);
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
 			a.O = s.rb[2][0].p;
 			a.E = s.rb[0][q].p; a.Ea = s.ub[1][q].p;
-			outs[i] = a.O;
-			return launch_fused(h, s, KF_B1L, a);
+			return a;
 		}));
-		CHK(exchange_halo(h, outs));
 		CHK(reduce_sums(h, PH_BL2));
 		// --- MR: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
 		CHK(for_slabs([&](Slab &s, int) -> int {
@@ -978,6 +1076,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	if (const char *e = getenv("KRY_TY")) h->ty = (atoi(e) == 8) ? 8 : 16;
 	if (const char *e = getenv("KRY_ZC")) { h->zc = std::max(1, atoi(e)); h->zc_fixed = true; }
 	if (const char *e = getenv("KRY_STREAM_BLOCKS")) h->stream_blocks = std::max(64, atoi(e));
+	if (const char *e = getenv("KRY_OVERLAP")) h->overlap = atoi(e) != 0;
 	if (const char *e = getenv("KRY_PROFILE")) h->profile = atoi(e) != 0;
 	h->slabs.resize(d->slab_count);
 	int st = 0;
@@ -988,8 +1087,11 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			s.device = d->devices[i];
 			HIPCHK(hipSetDevice(s.device));
 			HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+			HIPCHK(hipStreamCreateWithFlags(&s.st_comm, hipStreamNonBlocking));
 			HIPCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
 			HIPCHK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&s.ev_edge, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&s.ev_halo, hipEventDisableTiming));
 			KryGeo &g = s.g;
 			g.mx = d->mx[0]; g.my = d->mx[1]; g.mz = h->mzl;
 			g.px = ((g.mx + 4 + 15) / 16) * 16;
@@ -1069,6 +1171,9 @@ void kry_destroy(kry_handle h)
 		if (s.gather) hipFree(s.gather);
 		if (s.ev) hipEventDestroy(s.ev);
 		if (s.ev_in) hipEventDestroy(s.ev_in);
+		if (s.ev_edge) hipEventDestroy(s.ev_edge);
+		if (s.ev_halo) hipEventDestroy(s.ev_halo);
+		if (s.st_comm) hipStreamDestroy(s.st_comm);
 		if (s.st) hipStreamDestroy(s.st);
 	}
 	for (hipEvent_t e : h->prof.ev) hipEventDestroy(e);

@@ -82,3 +82,20 @@ def test_generic_path_on_slabs_mixed_faces(orc, nslabs, L):
     assert got["iters"] == 3
     assert np.max(np.abs(got["history"] - want["history"])) <= 1e-10 * want["norm_rhs"]
     assert rel_l2(points(got["phi"]), points(want["phi"])) <= 1e-10
+
+
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("nslabs", [2, 4])
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_split_launch_with_overlapped_exchange(orc, monkeypatch, L, overlap, nslabs):
+    """Short chunks force the edge/interior split of the stencil kernels, so the
+    halo exchange runs beside the interior chunks; results must not change."""
+    monkeypatch.setenv("KRY_ZC", "4")
+    monkeypatch.setenv("KRY_OVERLAP", overlap)
+    p = P.smooth_var(48)
+    p.rhs = np.random.default_rng(8).uniform(-1, 1, p.rhs.shape)
+    one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=6)
+    many = capi.solve_problem(p, L=L, eps=1e-30, max_outer=6, nslabs_local=nslabs, devices=(0,))
+    assert one["fused"] and many["fused"] and many["iters"] == 6
+    assert np.max(np.abs(one["history"] - many["history"])) <= 1e-10 * one["norm_rhs"]
+    assert rel_l2(points(many["phi"]), points(one["phi"])) <= 1e-10
