@@ -162,11 +162,27 @@ def main():
     device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank))
     solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
                          slab_begin=rank, slab_count=1, devices=(device,))
+    transport = "none"
     if world > 1:
         import torch
-        uid = [capi.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        solver.comm_init(uid[0], rank, world)
+        transport = "rccl"
+        try:
+            uid = [capi.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            solver.comm_init(uid[0], rank, world)
+            ok_local = 1
+        except Exception as e:           # no usable RCCL: keep the run alive on a host-staged path
+            sys.stderr.write("rank %d: RCCL communicator unavailable (%s)\n" % (rank, e))
+            ok_local = 0
+        flag = torch.tensor([ok_local])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            from krylov_amd import gloo_transport
+            transport = "gloo-staged (RCCL unavailable)"
+            solver.close()
+            solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
+                                 slab_begin=rank, slab_count=1, devices=(device,))
+            solver.comm_init_callbacks(rank, world, *gloo_transport.make(rank, world))
 
     def barrier():
         if dist is not None:
@@ -232,7 +248,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d^3 fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), Dirichlet faces, "
                                    "%d z-slab(s)" % (n, "variable" if var else "constant", L, world),
-                       "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world},
+                       "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world,
+                       "transport": transport},
             "valid": bool(ok),
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),

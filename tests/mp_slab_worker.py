@@ -6,7 +6,6 @@ RCCL transport drives on a multi-GPU node).
 
 usage: mp_slab_worker.py RANK WORLD PORT KIND L MAX_OUTER EPS OUTDIR
 """
-import ctypes as C
 import os
 import sys
 
@@ -25,49 +24,12 @@ def main():
     # the solver library (and with it the ROCm HIP runtime) before torch
     from krylov_amd import capi, problems as P
     capi.lib()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipMemcpy.restype = C.c_int
-    D2H, H2D = 2, 1
-
-    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    def to_host(dev, n):
-        t = torch.empty(n, dtype=torch.float64)
-        assert hip.hipMemcpy(t.data_ptr(), dev, n * 8, D2H) == 0
-        return t
-
-    def to_dev(dev, t):
-        assert hip.hipMemcpy(dev, t.data_ptr(), t.numel() * 8, H2D) == 0
-
-    def allreduce(buf, n):
-        t = to_host(buf, n)
-        # sum in rank order on every rank: gather, then add
-        parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(parts, t)
-        acc = parts[0].clone()
-        for q in parts[1:]:
-            acc += q
-        to_dev(buf, acc)
-
-    def halo(plo, slo, rlo, phi_, shi, rhi, count):
-        reqs, got = [], []
-        if plo >= 0:
-            s, r = to_host(slo, count), torch.empty(count, dtype=torch.float64)
-            reqs += [dist.isend(s, plo), dist.irecv(r, plo)]
-            got.append((rlo, r))
-        if phi_ >= 0:
-            s, r = to_host(shi, count), torch.empty(count, dtype=torch.float64)
-            reqs += [dist.isend(s, phi_), dist.irecv(r, phi_)]
-            got.append((rhi, r))
-        for q in reqs:
-            q.wait()
-        for dev, r in got:
-            to_dev(dev, r)
+    from krylov_amd import gloo_transport
+    allreduce, halo = gloo_transport.make(rank, world)
 
     import slab_reference as SR
     from test_gpu_multiproc import make_problem
