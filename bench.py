@@ -46,7 +46,7 @@ def kernel_words(L, var, offd):
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
             1: 11 + d,             # r1,u1,lam,rt,phi,u0,r0 -> u1,u2,phi,u0
             4: 8 + d,              # r1,u2,lam,r0,u1 -> r1,r2,r0
-            6: 4,                  # r2,r1,r0 -> r2
+            6: 3,                  # r2,r1,r0 -> dots only (r2' is recomputed by the last kernel)
             7: 11}                 # phi,r0..r2,u0..u2,rt -> phi,r0,u0
 
 

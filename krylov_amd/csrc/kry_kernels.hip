@@ -602,8 +602,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 // streaming kernels of the MR part (no stencil): one block per plane segment
 // ---------------------------------------------------------------------------
 
-// l = 2 modified Gram-Schmidt step: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
-// (solveLin_BICGStab.C:420-428, jj = 2)
+// l = 2 modified Gram-Schmidt step: r2' = r2 - tau12*r1 ; (r2',r2'), (r0,r2')
+// (solveLin_BICGStab.C:420-428, jj = 2).  r2' is not written back: its only other
+// use is the r0 update of k_final, which recomputes it from r2 and r1 with the
+// same two roundings, and r2 is overwritten by the next pass before any other read.
 __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 {
 	KryState *S = a.S;
@@ -627,8 +629,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 		for (int i = 0; i < UN; ++i) {
 			const long q = q0 + 2L * i * NT;
 			if (q < a.g.ps) {
-				r2[i] = axpy2(r2[i], r1[i], ntau);
-				st2s(a.w[0] + pb + q, r2[i]);
+				r2[i] = axpy2(r2[i], r1[i], ntau);   // kept in registers only: k_final recomputes it
 				if (cnt) {
 					acc[0] += r2[i].x * r2[i].x; acc[0] += r2[i].y * r2[i].y;
 					acc[1] += r0[i].x * r2[i].x; acc[1] += r0[i].y * r2[i].y;
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 	KryState *S = a.S;
 	if (S->done) return;
 	const double alpha = S->alpha;
+	const double ntau12 = (L == 2) ? -S->tau[1][2] : 0.;
 	double g1[L + 1], gp[L + 1], gpp[L + 1];
 #pragma unroll
 	for (int j = 1; j <= L; ++j) { g1[j] = S->gamma[j]; gp[j] = S->gammap[j]; gpp[j] = (j < L) ? S->gammapp[j] : 0.; }
@@ -676,6 +678,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			const long q = q0 + 2L * i * NT;
 			if (q < a.g.ps) {
 				const long p = pb + q;
+				if (L == 2) r[i][2] = axpy2(r[i][2], r[i][1], ntau12);   // the Gram-Schmidt step of k_mgs2
 				double2 phv = axpy2(ph[i], u[i][0], alpha);
 				phv = axpy2(phv, r[i][0], g1[1]);
 				double2 r0 = axpy2(r[i][0], r[i][L], -gp[L]);

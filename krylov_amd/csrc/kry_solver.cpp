@@ -237,7 +237,10 @@ int reduce_sums(kry_solver *h, int phase)
 	const bool remote = h->comm.active();
 	if (ns == 1 && !remote) return 0;
 	Slab &s0 = h->slabs[0];
-	double *tot = s0.S->sums;
+	// The total is formed in a buffer of its own (the first slab's `gather` tail):
+	// S->sums of a slab is rewritten by that slab's next reducing kernel, which
+	// may finish before a slower slab has fetched the total.
+	double *tot = (ns > 1) ? s0.gather + (size_t)KRY_MAX_SLABS * KRY_NSUMS : s0.S->sums;
 	if (ns > 1) {
 		for (int i = 0; i < ns; ++i) {
 			Slab &s = h->slabs[i];
@@ -253,10 +256,10 @@ int reduce_sums(kry_solver *h, int phase)
 	if (remote) CHK(h->comm.allreduce_sum(tot, KRY_NSUMS, s0.st));
 	if (ns > 1) {
 		HIPCHK(hipEventRecord(s0.ev_in, s0.st));
-		for (int i = 1; i < ns; ++i) {
+		for (int i = 0; i < ns; ++i) {
 			Slab &s = h->slabs[i];
 			HIPCHK(hipSetDevice(s.device));
-			HIPCHK(hipStreamWaitEvent(s.st, s0.ev_in, 0));
+			if (i > 0) HIPCHK(hipStreamWaitEvent(s.st, s0.ev_in, 0));
 			HIPCHK(hipMemcpyAsync(s.S->sums, tot, KRY_NSUMS * sizeof(double), hipMemcpyDeviceToDevice, s.st));
 		}
 	}
@@ -1126,7 +1129,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			HIPCHK(hipMalloc((void **)&s.partial, s.partial_cap * sizeof(double)));
 			HIPCHK(hipMalloc((void **)&s.counter, 64));
 			HIPCHK(hipMemsetAsync(s.counter, 0, 64, s.st));
-			HIPCHK(hipMalloc((void **)&s.gather, sizeof(double) * KRY_NSUMS * KRY_MAX_SLABS));
+			HIPCHK(hipMalloc((void **)&s.gather, sizeof(double) * KRY_NSUMS * (KRY_MAX_SLABS + 1)));
 			HIPCHK(hipStreamSynchronize(s.st));
 		}
 		// peer access between the devices of neighbouring local slabs

@@ -8,11 +8,7 @@ print('it/s',d['value'],'ms',d['ms_per_step'],'GB/s',d['iteration_GBps'],'frac',
 print('   '+'  '.join('%s %.0f'%(k,v['GBps']) for k,v in d['kernels'].items()))
 "
 }
+timeout -k 10 300 python -u -m pytest tests/test_gpu_bitwise.py tests/test_gpu_slabs.py -m gpu -q -x --timeout 300 --timeout-method thread 2>&1 | tail -2
 run
-run --ell 1
 run --workload const
-run --workload const --ell 1
 run --grid 256
-run --grid 256 --ell 1
-run --grid 256 --workload const
-run --grid 256 --workload const --ell 1
