@@ -4,6 +4,7 @@
 #include "kry_device.h"
 
 #define KRY_TXW 128   // fused tile width in grid points
+#define KRY_WDOT_BLOCKS 4096   // largest grid of the generic weighted dot
 #define KRY_SEG 2048  // doubles of a plane handled per block and plane by the streaming kernels
 
 // fused stencil kernel kinds

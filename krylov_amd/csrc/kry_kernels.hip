@@ -16,6 +16,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 #define NT 256                 // threads per block in every kernel here
 #define NW (NT / 64)           // wavefronts per block
 #define TXW KRY_TXW            // tile width in grid points = one 1 KiB wave load of double2
@@ -781,51 +783,65 @@ __global__ void g_bc(double *d, KryGeo g, int dir)
 }
 
 // Krylov::multiply_withMat on every point 0..m of the slab, neighbours read
-// from memory (ghosts included).  Grid: x over i, y over j, z over k.
+// from memory (ghosts included).  A block owns 4 grid rows (one per wave) and
+// walks them in 64-point strips; blockIdx.y counts row groups over (j,k).
 template <bool VAR, bool OFFD, bool EXACT>
 __global__ __launch_bounds__(NT) void g_spmv(KryGeo g, KryOp op, const double *psi, const double *lam,
                                              const double *Dxx, const double *Dyy, const double *Dzz,
                                              const double *Dxy, double *out)
 {
-	const int i = blockIdx.x * NT + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-	if (i > g.mx) return;
-	const long p = kry_idx(g, i, j, k), sx = g.px, sz = g.ps;
-	Sten s;
-	s.pc = psi[p]; s.xm = psi[p - 1]; s.xp = psi[p + 1];
-	s.ym = psi[p - sx]; s.yp = psi[p + sx]; s.zm = psi[p - sz]; s.zp = psi[p + sz];
-	s.lam = lam[p];
-	if (VAR) {
-		s.dxx = Dxx[p]; s.dyy = Dyy[p]; s.dzz = Dzz[p];
-		s.dxx_m = Dxx[p - 1]; s.dxx_p = Dxx[p + 1];
-		s.dyy_m = Dyy[p - sx]; s.dyy_p = Dyy[p + sx];
-		s.dzz_m = Dzz[p - sz]; s.dzz_p = Dzz[p + sz];
-		if (OFFD) {
-			s.dxy = Dxy[p];
-			s.dxy_xm = Dxy[p - 1]; s.dxy_xp = Dxy[p + 1];
-			s.dxy_ym = Dxy[p - sx]; s.dxy_yp = Dxy[p + sx];
-			s.pmm = psi[p - 1 - sx]; s.pmp = psi[p - 1 + sx];
-			s.ppm = psi[p + 1 - sx]; s.ppp = psi[p + 1 + sx];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const long rows = (long)(g.my + 1) * (g.mz + 1);
+	const long sx = g.px, sz = g.ps;
+	for (long row = (long)blockIdx.x * NW + w; row < rows; row += (long)gridDim.x * NW) {
+		const int j = (int)(row % (g.my + 1)), k = (int)(row / (g.my + 1));
+		const long p0 = kry_idx(g, 0, j, k);
+		for (int i = lane; i <= g.mx; i += 64) {
+			const long p = p0 + i;
+			Sten s;
+			s.pc = psi[p]; s.xm = psi[p - 1]; s.xp = psi[p + 1];
+			s.ym = psi[p - sx]; s.yp = psi[p + sx]; s.zm = psi[p - sz]; s.zp = psi[p + sz];
+			s.lam = lam[p];
+			if (VAR) {
+				s.dxx = Dxx[p]; s.dyy = Dyy[p]; s.dzz = Dzz[p];
+				s.dxx_m = Dxx[p - 1]; s.dxx_p = Dxx[p + 1];
+				s.dyy_m = Dyy[p - sx]; s.dyy_p = Dyy[p + sx];
+				s.dzz_m = Dzz[p - sz]; s.dzz_p = Dzz[p + sz];
+				if (OFFD) {
+					s.dxy = Dxy[p];
+					s.dxy_xm = Dxy[p - 1]; s.dxy_xp = Dxy[p + 1];
+					s.dxy_ym = Dxy[p - sx]; s.dxy_yp = Dxy[p + sx];
+					s.pmm = psi[p - 1 - sx]; s.pmp = psi[p - 1 + sx];
+					s.ppm = psi[p + 1 - sx]; s.ppp = psi[p + 1 + sx];
+				}
+			}
+			out[p] = apply_op<VAR, OFFD, EXACT>(s, op);
 		}
 	}
-	out[p] = apply_op<VAR, OFFD, EXACT>(s, op);
 }
 
 // Weighted dot product / squared norm over points 0..m (Krylov.C:161-244, 36-157):
 // faces 1/2, edges 1/4, corners 1/8 (dot) or 1/4 (norm).  Slab interfaces are
-// counted once, by the lower slab.
+// counted once, by the lower slab.  Wave w of block b takes grid rows
+// 4b+w, 4b+w+4*gridDim.x, ...; a lane takes points lane, lane+64, ... of a row.
 __global__ __launch_bounds__(NT) void g_wdot(KryGeo g, const double *x, const double *y, int norm_mode,
                                              KryRed red)
 {
-	const int i = blockIdx.x * NT + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const long rows = (long)(g.my + 1) * (g.mz + 1);
 	double acc[1] = {0.};
-	if (i <= g.mx) {
-		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
+	for (long row = (long)blockIdx.x * NW + w; row < rows; row += (long)gridDim.x * NW) {
+		const int j = (int)(row % (g.my + 1)), k = (int)(row / (g.my + 1));
+		const bool by = (j == 0 || j == g.my);
 		const bool bz = (k == 0 && !g.has_lo) || (k == g.mz && !g.has_hi);
-		double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
-		if (norm_mode && bx && by && bz) wgt = 0.25;
-		if (k == 0 && g.has_lo) wgt = 0.;
-		const long p = kry_idx(g, i, j, k);
-		acc[0] = wgt * (x[p] * y[p]);
+		if (k == 0 && g.has_lo) continue;
+		const long p0 = kry_idx(g, 0, j, k);
+		for (int i = lane; i <= g.mx; i += 64) {
+			const bool bx = (i == 0 || i == g.mx);
+			double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
+			if (norm_mode && bx && by && bz) wgt = 0.25;
+			acc[0] += wgt * (x[p0 + i] * y[p0 + i]);
+		}
 	}
 	reduce_and_finalize<1>(acc, red);
 }
@@ -918,7 +934,8 @@ hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool off
                             const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
                             const double *Dxy, double *out, hipStream_t st)
 {
-	dim3 grid(cdiv(g.mx + 1, NT), g.my + 1, g.mz + 1), block(NT);
+	const long rows = (long)(g.my + 1) * (g.mz + 1);
+	dim3 grid((unsigned)std::min<long>((rows + NW - 1) / NW, 16384)), block(NT);
 	const bool ex = op.exact_rcp;
 #define KRY_G(V, O, E) hipLaunchKernelGGL((g_spmv<V, O, E>), grid, block, 0, st, g, op, psi, lam, Dxx, Dyy, Dzz, Dxy, out)
 	if (!var) KRY_G(false, false, true);
@@ -931,8 +948,9 @@ hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool off
 hipError_t kry_launch_wdot(const KryGeo &g, const double *x, const double *y, int norm_mode, KryRed red,
                            hipStream_t st)
 {
-	dim3 grid(cdiv(g.mx + 1, NT), g.my + 1, g.mz + 1), block(NT);
-	red.nblk = (int)(grid.x * grid.y * grid.z);
+	const long rows = (long)(g.my + 1) * (g.mz + 1);
+	dim3 grid((unsigned)std::min<long>((rows + NW - 1) / NW, KRY_WDOT_BLOCKS)), block(NT);
+	red.nblk = (int)grid.x;
 	hipLaunchKernelGGL(g_wdot, grid, block, 0, st, g, x, y, norm_mode, red);
 	return hipGetLastError();
 }

@@ -145,30 +145,34 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B)
 	return v;
 }
 
-/* generic weighted dot: g_wdot */
+/* generic weighted dot: g_wdot (wave w of block b walks grid rows 4b+w, +4*nblk, ...;
+ * a lane takes points lane, lane+64, ... of each row) */
 static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int norm_mode)
 {
 	const hbox b = hb(c);
-	const int gx = (b.mx + 1 + NT - 1) / NT, gy = b.my + 1, gz = b.mz + 1;
-	const long nblk = (long)gx * gy * gz;
+	const long rows = (long)(b.my + 1) * (b.mz + 1);
+	long nblk = (rows + NW - 1) / NW;
+	if (nblk > 4096) nblk = 4096;
 	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
-	for (int k = 0; k < gz; ++k)
-		for (int j = 0; j < gy; ++j)
-			for (int bx = 0; bx < gx; ++bx) {
-				double acc[NT];
-				for (int t = 0; t < NT; ++t) {
-					const int i = bx * NT + t;
-					double s = 0.;
-					if (i <= b.mx) {
-						const int fx = (i == 0 || i == b.mx), fy = (j == 0 || j == b.my), fz = (k == 0 || k == b.mz);
-						double wgt = (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
-						if (norm_mode && fx && fy && fz) wgt = 0.25;
-						s = wgt * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
-					}
-					acc[t] = s;
+	for (long blk = 0; blk < nblk; ++blk) {
+		double acc[NT];
+		for (int t = 0; t < NT; ++t) {
+			const int lane = t & 63, w = t >> 6;
+			double s = 0.;
+			for (long row = blk * NW + w; row < rows; row += nblk * NW) {
+				const int j = (int)(row % (b.my + 1)), k = (int)(row / (b.my + 1));
+				const int fy = (j == 0 || j == b.my), fz = (k == 0 || k == b.mz);
+				for (int i = lane; i <= b.mx; i += 64) {
+					const int fx = (i == 0 || i == b.mx);
+					double wgt = (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
+					if (norm_mode && fx && fy && fz) wgt = 0.25;
+					s += wgt * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
 				}
-				partial[bx + (long)gx * (j + (long)gy * k)] = block_total(acc);
 			}
+			acc[t] = s;
+		}
+		partial[blk] = block_total(acc);
+	}
 	double v = grid_total(partial, nblk);
 	free(partial);
 	return v;
