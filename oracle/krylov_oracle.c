@@ -89,19 +89,26 @@ static long long time_ms(void)
  * Krylov.C:259,325.  They act on the full stored extent, ghosts included, and
  * `x -= y*s` materialises the product in a temporary first. */
 
+/* The loops below carry OpenMP pragmas that only the separate -fopenmp build
+ * (libkrylov_oracle_omp.so, the multi-core CPU baseline of bench.py) honours.
+ * The parity oracle is the plain single-thread build: there the pragmas are
+ * ignored and every sum runs in the reference's order. */
 static void arr_scale(long n, double *a, double s)
 {
+	_Pragma("omp parallel for")
 	for (long i = 0; i < n; ++i) a[i] *= s;
 }
 
 static void arr_add(long n, double *a, const double *b)
 {
+	_Pragma("omp parallel for")
 	for (long i = 0; i < n; ++i) a[i] += b[i];
 }
 
 static double *arr_times(long n, const double *b, double s)
 {
 	double *t = (double *)malloc((size_t)n * sizeof(double));
+	_Pragma("omp parallel for")
 	for (long i = 0; i < n; ++i) t[i] = b[i] * s;
 	return t;
 }
@@ -109,6 +116,7 @@ static double *arr_times(long n, const double *b, double s)
 static void arr_sub_scaled(long n, double *a, const double *b, double s)
 {
 	double *t = arr_times(n, b, s);
+	_Pragma("omp parallel for")
 	for (long i = 0; i < n; ++i) a[i] -= t[i];
 	free(t);
 }
@@ -116,6 +124,7 @@ static void arr_sub_scaled(long n, double *a, const double *b, double s)
 static void arr_add_scaled(long n, double *a, const double *b, double s)
 {
 	double *t = arr_times(n, b, s);
+	_Pragma("omp parallel for")
 	for (long i = 0; i < n; ++i) a[i] += t[i];
 	free(t);
 }
@@ -218,6 +227,7 @@ double orc_l2norm(const orc_cfg *c, const double *v)
 	(void)sink;
 
 	double mymax = -10;
+	_Pragma("omp parallel for reduction(max : mymax)")
 	for (int iz = 0; iz <= mz; iz++)
 		for (int iy = 0; iy <= my; iy++)
 			for (int ix = 0; ix <= mx; ix++) {
@@ -230,6 +240,7 @@ double orc_l2norm(const orc_cfg *c, const double *v)
 	double scaleFactor = 1. / valMax;
 
 	ORC_ACC sum = 0.;
+	_Pragma("omp parallel for reduction(+ : sum)")
 	for (int iz = 1; iz < mz; iz++)
 		for (int iy = 1; iy < my; iy++)
 			for (int ix = 1; ix < mx; ix++) {
@@ -292,6 +303,7 @@ double orc_dot(const orc_cfg *c, const double *A, const double *B)
 	const int mx = b.mx, my = b.my, mz = b.mz;
 	ORC_ACC result = 0.;
 
+	_Pragma("omp parallel for reduction(+ : result)")
 	for (int iz = 1; iz < mz; iz++)
 		for (int iy = 1; iy < my; iy++)
 			for (int ix = 1; ix < mx; ix++)
@@ -356,6 +368,7 @@ void orc_spmv_const(const orc_cfg *c, double *psi, const double *lambda,
 
 	orc_do_bcs(c, psi);
 
+	_Pragma("omp parallel for")
 	for (int iz = 0; iz <= b.mz; iz++)
 		for (int iy = 0; iy <= b.my; iy++)
 			for (int ix = 0; ix <= b.mx; ix++) {
@@ -383,6 +396,7 @@ void orc_spmv_var(const orc_cfg *c, const double *psi, const double *lambda,
 	for (int d = 0; d < 3; ++d) coeff[d] = 1. / sqr(delx[d]);
 	const double coeff_xy = 1. / (2. * delx[0] * delx[1]);
 
+	_Pragma("omp parallel for")
 	for (int iz = 0; iz <= b.mz; iz++)
 		for (int iy = 0; iy <= b.my; iy++)
 			for (int ix = 0; ix <= b.mx; ix++) {
@@ -435,6 +449,7 @@ static void residual(const orc_cfg *c, double *phi, const double *rhs, const dou
 	else             orc_spmv_const(c, phi, lambda, res, 0);
 	/* residual = rhs - residual: temporary, then assignment */
 	double *t = (double *)malloc((size_t)b.n * sizeof(double));
+	_Pragma("omp parallel for")
 	for (long i = 0; i < b.n; ++i) t[i] = rhs[i] - res[i];
 	memcpy(res, t, (size_t)b.n * sizeof(double));
 	free(t);

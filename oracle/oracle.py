@@ -50,6 +50,18 @@ def build(force=False):
 
 
 _lib = None
+_OMP_LIB = os.path.join(_HERE, "libkrylov_oracle_omp.so")
+
+
+def use_openmp_build():
+    """Switch this module to the -fopenmp build of the same sources (CPU
+    baseline timing only; its sums are not in the reference's order)."""
+    global _lib, _LIB
+    if not os.path.exists(_OMP_LIB):
+        build(force=True)
+    _LIB, _lib = _OMP_LIB, None
+
+
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
