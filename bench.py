@@ -172,7 +172,8 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
-    os.environ.setdefault("KRY_PROFILE", "1")
+    # per-kernel HIP events only where the roofline is reported (one GPU)
+    os.environ.setdefault("KRY_PROFILE", "1" if world == 1 else "0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # the solver library first (it binds the ROCm installation's HIP runtime),

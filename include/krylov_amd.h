@@ -97,6 +97,12 @@ void       kry_destroy(kry_handle h);
 int kry_comm_unique_id(void *uid /* KRY_UID_BYTES */);
 int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks);
 
+/* Exercises the RCCL transport on a single device: a one-rank communicator, an
+ * in-place all-reduce and a grouped send/receive to itself, each checked against
+ * the expected data.  Returns KRY_OK, or KRY_ERR_COMM with kry_last_error() set.
+ * (No counterpart in the reference; a deployment check.) */
+int kry_comm_selftest(int device);
+
 /* The same role with the caller's own transport instead of RCCL, e.g. the
  * MPI communicator of a `-D parallel` build (the reference exchanges faces with
  * MPI_Isend/MPI_Irecv, BICGStab3D/BoundaryHandler.C:1633-1677, and reduces with

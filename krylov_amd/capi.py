@@ -22,7 +22,7 @@ STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reache
 # every symbol include/krylov_amd.h declares
 SYMBOLS = [
     "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks",
-    "kry_solve_const",
+    "kry_comm_selftest", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
     "kry_get_stats", "kry_get_history", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
@@ -95,6 +95,8 @@ def lib():
     L.kry_comm_unique_id.argtypes = [vp]
     L.kry_comm_init.restype = ci
     L.kry_comm_init.argtypes = [vp, vp, ci, ci]
+    L.kry_comm_selftest.restype = ci
+    L.kry_comm_selftest.argtypes = [ci]
     L.kry_comm_init_callbacks.restype = ci
     L.kry_comm_init_callbacks.argtypes = [vp, ci, ci, ALLREDUCE_CB, HALO_CB, vp]
     L.kry_solve_const.restype = ci
@@ -140,6 +142,10 @@ def _check(st, what):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def comm_selftest(device=0):
+    return _check(lib().kry_comm_selftest(int(device)), "kry_comm_selftest")
 
 
 def unique_id():

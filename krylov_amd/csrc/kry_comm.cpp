@@ -150,3 +150,38 @@ int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_
 	NCHK(g_api.GroupEnd());
 	return 0;
 }
+
+int KryComm::selftest()
+{
+	ncclUniqueId id;
+	if (unique_id(&id) < 0) return -3;
+	KryComm c;
+	if (c.init(&id, 0, 1) < 0) return -3;
+	const int n = 4096;
+	double *d = nullptr;
+	std::string err;
+	auto bad = [&](const char *m) { err = m; };
+	if (hipMalloc((void **)&d, 3 * n * sizeof(double)) != hipSuccess) { g_cerr = "hipMalloc failed"; c.destroy(); return -2; }
+	double *host = new double[3 * n];
+	for (int i = 0; i < n; ++i) { host[i] = 1.0 + i; host[n + i] = 1000.0 + i; host[2 * n + i] = -1.0; }
+	hipStream_t st;
+	hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+	hipMemcpyAsync(d, host, 3 * n * sizeof(double), hipMemcpyHostToDevice, st);
+	int rc = c.allreduce_sum(d, 8, st);                       // one rank: values unchanged
+	if (rc == 0) rc = c.halo(0, d + n, d + 2 * n, -1, nullptr, nullptr, (size_t)n, st);   // to itself
+	if (rc == 0) {
+		hipMemcpyAsync(host, d, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st);
+		if (hipStreamSynchronize(st) != hipSuccess) bad("stream synchronize failed");
+		for (int i = 0; i < 8 && err.empty(); ++i)
+			if (host[i] != 1.0 + i) bad("all-reduce changed the data of a one-rank communicator");
+		for (int i = 0; i < n && err.empty(); ++i)
+			if (host[2 * n + i] != 1000.0 + i) bad("send/receive to self delivered wrong data");
+	}
+	hipStreamDestroy(st);
+	hipFree(d);
+	delete[] host;
+	c.destroy();
+	if (rc < 0) return rc;
+	if (!err.empty()) { g_cerr = err; return -3; }
+	return 0;
+}

@@ -11,6 +11,8 @@ public:
 	// 128-byte id created on one rank and handed to every rank's init()
 	static int unique_id(void *uid);
 	static const char *last_error();
+	// one-rank communicator on the current device: all-reduce + self send/recv, verified
+	static int selftest();
 
 	int init(const void *uid, int rank, int nranks);
 	// caller-provided transport (device pointers, blocking); see include/krylov_amd.h

@@ -144,9 +144,9 @@ __device__ inline double wave_sum(double v)
 // block that is), publishes them in S->sums and, when the solver runs on one
 // slab, advances the scalar recurrences.  The partials travel between blocks
 // as agent-scope (write-through / cache-bypassing) stores and loads, so no
-// cache write-back or invalidate is needed around the ticket: stores, vmcnt
-// drain, barrier, relaxed agent-scope ticket; the last block reads every
-// partial with agent-scope loads.
+// cache write-back is needed around the ticket: stores, vmcnt drain, barrier,
+// relaxed agent-scope ticket; the last block issues one agent-scope acquire and
+// reads the partials with ordinary loads.
 __device__ inline void pub_store(double *p, double v)
 {
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -185,12 +185,20 @@ __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, i
 	__syncthreads();
 	if (!is_last) return;
 
+	// one agent-scope acquire for the block, then ordinary (pipelined) loads
+	if (tid == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
 	double tot[ND];
 #pragma unroll
 	for (int k = 0; k < ND; ++k) tot[k] = 0.;
+	const double *part = r.partial;
+#pragma unroll 4
 	for (int b = tid; b < r.nblk; b += NT) {
 #pragma unroll
-		for (int k = 0; k < ND; ++k) tot[k] += pub_load(&r.partial[(long)b * ND + k]);
+		for (int k = 0; k < ND; ++k) tot[k] += part[(long)b * ND + k];
 	}
 	__syncthreads();
 #pragma unroll

@@ -423,7 +423,7 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 	return 0;
 }
 
-KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby)
+KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby, int min_planes)
 {
 	KryStream a;
 	memset(&a, 0, sizeof a);
@@ -436,9 +436,11 @@ KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby)
 	a.nplanes = zl - zf + 1;
 	a.cnt_lo = 1;
 	a.cnt_hi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
-	// about 2048 blocks: segments of a plane in x, groups of planes in y
+	// segments of a plane in x, groups of planes in y
 	*nbx = (int)((s.g.ps + KRY_SEG - 1) / KRY_SEG);
-	*nby = std::max(1, std::min(a.nplanes, (h->stream_blocks + *nbx - 1) / *nbx));
+	// min_planes per block: the read-only kernel amortises its end-of-block reduction
+	// over several planes, the store-heavy one runs best with short-lived blocks
+	*nby = std::max(1, std::min(std::max(1, a.nplanes / min_planes), (h->stream_blocks + *nbx - 1) / *nbx));
 	a.red = make_red(s, (*nbx) * (*nby), phase);
 	return a;
 }
@@ -554,7 +556,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- MR: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
 		CHK(for_slabs([&](Slab &s, int) -> int {
 			int nbx, nby;
-			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby);
+			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby, 4);
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
 			a.w[0] = s.rb[2][0].p;
 			HIPCHK(hipSetDevice(s.device));
@@ -569,7 +571,7 @@ int fused_pass(kry_solver *h, int it)
 	// --- end of pass: phi, r0, u0 updates ; |r0|^2, (r0, r~)
 	CHK(for_slabs([&](Slab &s, int) -> int {
 		int nbx, nby;
-		KryStream a = stream_base(h, s, PH_F, &nbx, &nby);
+		KryStream a = stream_base(h, s, PH_F, &nbx, &nby, 1);
 		if (L == 1) {
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][0].p;
 			a.v[2] = s.ub[0][q].p; a.v[3] = s.ub[1][0].p;
@@ -1200,6 +1202,14 @@ int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks)
 	}
 	hipSetDevice(h->slabs[0].device);
 	int st = h->comm.init(uid, rank, nranks);
+	if (st < 0) set_err("%s", KryComm::last_error());
+	return st;
+}
+
+int kry_comm_selftest(int device)
+{
+	if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return KRY_ERR_HIP; }
+	int st = KryComm::selftest();
 	if (st < 0) set_err("%s", KryComm::last_error());
 	return st;
 }

@@ -107,14 +107,15 @@ static double fused_sum(const orc_cfg *c, const double *A, const double *B)
 }
 
 /* streaming kernels: k_final, k_mgs2 */
-static double stream_sum(const orc_cfg *c, const double *A, const double *B)
+static double stream_sum(const orc_cfg *c, const double *A, const double *B, int min_planes)
 {
 	const hbox b = hb(c);
 	const long px = ((b.mx + 4 + 15) / 16) * 16, ps = px * (b.my + 3);
 	const int nbx = (int)((ps + 2047) / 2048);
 	const int nplanes = b.mz - 1;
 	int nby = (g_sb + nbx - 1) / nbx;
-	if (nby > nplanes) nby = nplanes;
+	const int cap = nplanes / min_planes > 1 ? nplanes / min_planes : 1;   /* planes per block: 4 in k_mgs2, 1 in k_final */
+	if (nby > cap) nby = cap;
 	if (nby < 1) nby = 1;
 	const long nblk = (long)nbx * nby;
 	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
@@ -191,13 +192,13 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 	case ORC_SITE_NORM_INIT: return sqrt(fused_sum(c, a, b));          /* residual kernel */
 	case ORC_SITE_RHO:
 		if (jj == 0) return iter == 1 ? fused_sum(c, a, b)                /* |r0|^2 of the residual kernel */
-		                              : stream_sum(c, a, b);              /* end-of-pass kernel */
+		                              : stream_sum(c, a, b, 1);           /* end-of-pass kernel */
 		return fused_sum(c, a, b);                                        /* B kernel of jj-1 */
 	case ORC_SITE_ALPHA:     return fused_sum(c, a, b);                   /* A kernels */
 	case ORC_SITE_TAU:       return fused_sum(c, a, b);                   /* last B kernel */
 	case ORC_SITE_SIGMA:
-	case ORC_SITE_GAMMAP:    return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b);
-	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b));
+	case ORC_SITE_GAMMAP:    return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);   /* k_mgs2 */
+	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b, 1));
 	}
 	return orc_dot(c, a, b);
 }

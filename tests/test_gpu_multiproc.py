@@ -88,3 +88,11 @@ def test_processes_full_solve(tmp_path):
         assert int(d["status"]) == 0
         assert d["hist"][-1] <= 1e-6 * one["norm_rhs"]
         assert abs(int(d["iters"]) - one["iters"]) <= max(8, one["iters"] // 3)
+
+
+@gpu
+def test_rccl_transport_selftest():
+    """RCCL itself on this device: one-rank communicator, all-reduce, grouped
+    send/receive to self, data verified inside the library."""
+    from krylov_amd import capi
+    assert capi.comm_selftest(0) == 0
