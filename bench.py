@@ -65,12 +65,13 @@ def measured_traffic(kernel_name, n, L, workload, world):
     return None, None
 
 
-def slab_problem(n, nslabs, slab, workload):
-    """Fields of z-slab `slab` of the n^3 problem, ghost planes included,
-    evaluated from closed forms at global positions."""
+def slab_problem(n, nslabs, slab, workload, nz=None):
+    """Fields of z-slab `slab` of the n x n x nz problem (nz = n unless given),
+    ghost planes included, evaluated from closed forms at global positions."""
     from krylov_amd import problems as P
-    mzl = n // nslabs
-    delx = (1.0 / n,) * 3
+    nz = n if nz is None else nz
+    mzl = nz // nslabs
+    delx = (1.0 / n, 1.0 / n, 1.0 / nz)
     ax = [np.arange(-1, n + 2, dtype=np.float64) * delx[0],
           np.arange(-1, n + 2, dtype=np.float64) * delx[1],
           (np.arange(-1, mzl + 2, dtype=np.float64) + slab * mzl) * delx[2]]
@@ -159,6 +160,8 @@ def main():
     ap.add_argument("--grid", dest="n", type=int, default=512, help="grid size (points 0..n per direction)")
     ap.add_argument("--ell", dest="L", type=int, default=2, help="BiCGStab(l) degree; the reference drivers use 2")
     ap.add_argument("--workload", choices=["var", "const"], default="var")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: a GRID x GRID x 128 block per GPU (GRID = 1024 gives the 1024^3 problem on 8 GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=192)
     ap.add_argument("--cpu-iters", type=int, default=4)
@@ -187,9 +190,10 @@ def main():
         dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
 
     n, L, var = args.n, args.L, args.workload == "var"
-    if n % world != 0:
-        sys.exit("grid size %d is not divisible by %d slabs" % (n, world))
-    f = slab_problem(n, world, rank, args.workload)
+    nz = 128 * world if args.weak else n
+    if nz % world != 0:
+        sys.exit("grid size %d is not divisible by %d slabs" % (nz, world))
+    f = slab_problem(n, world, rank, args.workload, nz)
 
     device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank))
     solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
@@ -249,7 +253,7 @@ def main():
     ok = (st == 0 and s1.iterations == args.warmup + args.steps and np.all(np.isfinite(hist)))
 
     if rank == 0:
-        npts = float(n + 1) ** 3
+        npts = float(n + 1) ** 2 * (nz + 1)
         words = kernel_words(L, var, False)
         kern = {}
         for k, w in words.items():
@@ -276,10 +280,11 @@ def main():
             "metric": "BiCGStab iters/sec + achieved HBM GB/s (fp64 512^3) at 1/2/4/8 MI355X",
             "value": round(args.steps / elapsed, 3), "unit": "iter/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d^3 fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), Dirichlet faces, "
-                                   "%d z-slab(s)" % (n, "variable" if var else "constant", L, world),
+            "config": {"workload": "%s fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), Dirichlet faces, "
+                                   "%d z-slab(s)" % ("%d^3" % n if nz == n else "%dx%dx%d" % (n, n, nz),
+                                                     "variable" if var else "constant", L, world),
                        "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world,
                        "transport": transport},
             "valid": bool(ok),
@@ -292,7 +297,7 @@ def main():
                                     "words": v["words"], "calls": v["calls"]} for v in kern.values()},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.weak:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, L, args.workload, n, args.cpu_iters)
         print(json.dumps(out), flush=True)
 

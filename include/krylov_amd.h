@@ -79,6 +79,7 @@ typedef struct kry_stats {
 	int    tile_rows;        /* launch geometry, which fixes the summation order of the dots: */
 	int    chunk_planes;     /*   rows per fused tile, planes per fused chunk,               */
 	int    stream_blocks;    /*   grid target of the streaming kernels                        */
+	double enqueue_ms;       /* host time spent queueing kernels and transfers of the passes  */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;

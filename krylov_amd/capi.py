@@ -61,6 +61,7 @@ class KryStats(C.Structure):
         ("tile_rows", C.c_int),
         ("chunk_planes", C.c_int),
         ("stream_blocks", C.c_int),
+        ("enqueue_ms", C.c_double),
     ]
 
 

@@ -110,6 +110,7 @@ struct kry_solver {
 	bool done = false;
 	double norm_rhs = 0, norm_init = 0, norm_final = 0;
 	double solve_ms = 0, stage_ms = 0;
+	double enqueue_ms = 0;     // host time spent queueing the passes of the last run
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
 	bool profile = false;
 	bool overlap = true;       // halo exchange concurrent with the interior chunks
@@ -942,6 +943,7 @@ int run_iterations(kry_solver *h, int n_outer)
 			const int it0 = h->it_base;
 			double t0 = now_ms();
 			for (int i = 0; i < nb; ++i) CHK(fused_pass(h, it0 + i));
+			h->enqueue_ms += now_ms() - t0;
 			CHK(poll_state(h));
 			if (h->debug > 2) {
 				Slab &s = h->slabs[0];
@@ -1009,6 +1011,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	}
 	h->loaded = true;
 	h->solve_ms = 0;
+	h->enqueue_ms = 0;
 	CHK(prologue(h));
 	CHK(sync_all(h));
 	h->stage_ms = now_ms() - t0;
@@ -1305,6 +1308,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	o->norm_final = h->norm_final;
 	o->solve_ms = h->solve_ms;
 	o->stage_ms = h->stage_ms;
+	o->enqueue_ms = h->enqueue_ms;
 	// algorithmic doubles moved per grid point and outer pass under the fully fused schedule
 	int W;
 	if (h->L == 1) W = h->var ? (h->offd ? 28 : 26) : 20;

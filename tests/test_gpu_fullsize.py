@@ -61,3 +61,21 @@ def test_converged_solution_has_small_true_residual(prob, L):
         r[:, :, 1] = r[:, :, -2] = 0
         nrm = s.op_l2norm(r)
     assert nrm <= 2e-6 * got["norm_rhs"]
+
+
+def test_weak_scaling_block_shape_1024x1024x128():
+    """The per-GPU block of the 1024^3 weak-scaling configuration: widest rows the
+    configs use (8 tiles per row).  Fused against generic operator, bit for bit,
+    and a few passes of the solve."""
+    import bench
+    f = bench.slab_problem(1024, 1, 0, "var", nz=128)
+    psi = np.random.default_rng(4).uniform(-1, 1, f["rhs"].shape)
+    with capi.Solver(f["mx"], f["delx"], (0,) * 6, L=2, eps=0.0) as s:
+        a = s.op_spmv_var(psi, f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False, fused=True)
+        b = s.op_spmv_var(psi, f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False, fused=False)
+        assert np.array_equal(points(a), points(b))
+        del a, b
+        s.load_var(f["phi"], f["rhs"], f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False)
+        assert s.iterate(5) == 0
+        h = s.history()
+    assert len(h) == 5 and np.all(np.isfinite(h)) and h[-1] < h[0]

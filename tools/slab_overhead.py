@@ -25,5 +25,7 @@ for P in (1, 2, 4, 8):
         t0 = time.perf_counter()
         s.iterate(20)
         dt = time.perf_counter() - t0
-        print("slabs %d overlap %s : %.2f it/s  %.3f ms/pass" % (P, ov, 20 / dt, dt / 20 * 1e3), flush=True)
+        st = s.stats()
+        print("slabs %d overlap %s : %.2f it/s  %.3f ms/pass   host enqueue %.3f ms/pass (%.3f per slab)"
+              % (P, ov, 20 / dt, dt / 20 * 1e3, st.enqueue_ms / 23, st.enqueue_ms / 23 / P), flush=True)
         s.close()
