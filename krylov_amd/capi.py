@@ -297,6 +297,6 @@ def solve_problem(p, L=2, eps=1e-6, max_outer=0, flags=0, nslabs_local=1, device
         stats = s.stats()
         hist = s.history()
     return dict(status=st, phi=phi, history=hist, iters=stats.iterations, norm_rhs=stats.norm_rhs,
-                norm_init=stats.norm_init, norm_final=stats.norm_final, fused=bool(stats.fused),
+                norm_init=stats.norm_init, norm_final=stats.norm_final, fused=bool(stats.fused), path=int(stats.fused),
                 solve_ms=stats.solve_ms, stage_ms=stats.stage_ms,
                 order=(stats.tile_rows, stats.chunk_planes, stats.stream_blocks))

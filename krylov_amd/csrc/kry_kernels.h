@@ -6,6 +6,7 @@
 #define KRY_TXW 128   // fused tile width in grid points
 #define KRY_WDOT_BLOCKS 4096   // largest grid of the generic weighted dot
 #define KRY_SEG 2048  // doubles of a plane handled per block and plane by the streaming kernels
+#define KRY_SURF_BLOCKS 512    // largest grid of the boundary-plane dot kernel
 
 // fused stencil kernel kinds
 enum KryFusedKind {
@@ -59,10 +60,13 @@ struct KryStream {
 	int zfirst;              // first plane processed
 	int nplanes;             // planes processed, strided over blockIdx.y
 	int cnt_lo, cnt_hi;      // planes that count in the dot products
+	int gen;                 // 1: general boundaries (weighted dots over the points 0..m)
 };
 
 hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact,
                             hipStream_t st);
+hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool offd, bool exact, hipStream_t st);
+hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st);
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);
 hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st);
 hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st);

@@ -324,7 +324,14 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // Tile: TXW points in x (one double2 per lane), TY rows, marched over a chunk of
 // planes.  psi of plane z lives in LDS buffer z&1 (tile + one halo ring), psi of
 // planes z-1, z, z+1 at the thread's own points lives in registers.
-template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT>
+//
+// GEN (general boundaries): the tiles cover the ghost-inclusive box in x and y
+// (first tile column 0, first tile row j = -1) and the planes -1 .. mz+1, because
+// the reference's whole-array vector updates (solveLin_BICGStab.C:356-362,
+// 392-394) act on ghost cells too and a later stencil reads them.  The operator
+// is evaluated on every point 0..m (Krylov.C:429-459); its boundary treatment
+// and the boundary-plane terms of the dot products follow in g_bc and k_surf.
+template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN>
 __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 {
 	constexpr int VD = TY / NW;                 // rows per thread
@@ -358,16 +365,22 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int z0 = a.zlo + ch * a.zc;
 	const int z1 = min(z0 + a.zc, a.zhi + 1);   // exclusive
-	const int y0 = ty * TY;                     // first row (grid index j) of the tile
-	const int c0 = 2 + tx * TXW;                // first column of the tile
+	const int y0 = ty * TY - (GEN ? 1 : 0);     // first row (grid index j) of the tile
+	const int c0 = (GEN ? 0 : 2) + tx * TXW;    // first column of the tile
 	const int col = c0 + 2 * lane;              // column of .x ; grid index i = col - 2
 	const int ix = col - 2;
+	// strict interior: the points that count in the dot products here
 	const bool mxx = (ix >= 1 && ix <= g.mx - 1);
 	const bool mxy = (ix + 1 >= 1 && ix + 1 <= g.mx - 1);
+	// cells whose vector updates are stored / points whose operator value is stored
+	const bool uxx = GEN ? (ix >= -1 && ix <= g.mx + 1) : mxx;
+	const bool uxy = GEN ? (ix + 1 >= -1 && ix + 1 <= g.mx + 1) : mxy;
+	const bool oxx = GEN ? (ix >= 0 && ix <= g.mx) : mxx;
+	const bool oxy = GEN ? (ix + 1 >= 0 && ix + 1 <= g.mx) : mxy;
 
 	long off[VD];        // in-plane offset of the own double2
 	int lidx[VD];        // LDS index of the own double2
-	bool mrow[VD];
+	bool mrow[VD], urow[VD], orow[VD];
 #pragma unroll
 	for (int e = 0; e < VD; ++e) {
 		const int r = w * VD + e;
@@ -375,6 +388,8 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		off[e] = (long)(j + 1) * g.px + col;
 		lidx[e] = (r + 1) * LW + 2 + 2 * lane;
 		mrow[e] = (j >= 1 && j <= g.my - 1);
+		urow[e] = GEN ? (j <= g.my + 1) : mrow[e];
+		orow[e] = GEN ? (j >= 0 && j <= g.my) : mrow[e];
 	}
 	// halo duties: waves 0,1 load the row above / below the tile, wave 2 the two columns
 	const bool hrow = tid < 128;
@@ -433,10 +448,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		const long pb = plane(z);
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
-			if (mrow[e]) {
-				if (mxx && mxy) st2s(a.Xout + pb + off[e], v[e]);
-				else if (mxx) a.Xout[pb + off[e]] = v[e].x;
-				else if (mxy) a.Xout[pb + off[e] + 1] = v[e].y;
+			if (urow[e]) {
+				if (uxx && uxy) st2s(a.Xout + pb + off[e], v[e]);
+				else if (uxx) a.Xout[pb + off[e]] = v[e].x;
+				else if (uxy) a.Xout[pb + off[e] + 1] = v[e].y;
 			}
 		}
 	};
@@ -449,20 +464,20 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			double2 u0 = ld2s(a.E + p), r0 = ld2s(a.Ea + p), ph = ld2s(a.phi + p);
 			ph = axpy2(ph, u0, alpha_prev);
 			double2 un = axpy2(r0, u0, cpsi);
-			if (mrow[e]) {
-				if (mxx && mxy) { st2s(a.phi + p, ph); st2s(a.E + p, un); }
-				else if (mxx) { a.phi[p] = ph.x; a.E[p] = un.x; }
-				else if (mxy) { a.phi[p + 1] = ph.y; a.E[p + 1] = un.y; }
+			if (urow[e]) {
+				if (uxx && uxy) { st2s(a.phi + p, ph); st2s(a.E + p, un); }
+				else if (uxx) { a.phi[p] = ph.x; a.E[p] = un.x; }
+				else if (uxy) { a.phi[p + 1] = ph.y; a.E[p + 1] = un.y; }
 			}
 			comp = un;
 		} else if (KIND == KF_B1L) {
 			// r0 -= alpha*u1 (:392-394, ii = 0 of jj = 1)
 			double2 r0 = ld2s(a.E + p), u1 = ld2s(a.Ea + p);
 			double2 rn = axpy2(r0, u1, cpsi);
-			if (mrow[e]) {
-				if (mxx && mxy) st2s(a.E + p, rn);
-				else if (mxx) a.E[p] = rn.x;
-				else if (mxy) a.E[p + 1] = rn.y;
+			if (urow[e]) {
+				if (uxx && uxy) st2s(a.E + p, rn);
+				else if (uxx) a.E[p] = rn.x;
+				else if (uxy) a.E[p + 1] = rn.y;
 			}
 			comp = rn;
 		}
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			dzc[e] = ld2(a.Dzz + plane(z0) + off[e]);
 		}
 	}
-	if (z0 == a.zlo && g.has_lo && z0 == 0) {   // plane -1 belongs to a neighbour: keep its ghosts current
+	if (z0 == a.zlo && (GEN || g.has_lo) && z0 == 0) {   // plane -1 is a neighbour's plane or a live ghost: keep it current
 		store_psi(pm, -1);
 		if (KIND == KF_A1 || KIND == KF_B1L) {
 #pragma unroll
@@ -496,14 +511,16 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		// 1. psi of plane z+1 -> registers, other LDS buffer, memory
 		own_psi(pp);
 		to_lds(pp, lds[(z + 1) & 1]);
-		if (z + 1 < z1 || (z + 1 == a.zhi + 1 && g.has_hi && a.zhi == g.mz)) store_psi(pp, z + 1);
+		if (z + 1 < z1 || (z + 1 == a.zhi + 1 && (GEN || g.has_hi) && a.zhi == g.mz)) store_psi(pp, z + 1);
 		// 2. prefetch the inputs of plane z+2
 		if (z + 1 < z1) issue(z + 2);
 
 		// 3. stencil on plane z
 		const long pb = plane(z);
 		const double *buf = lds[z & 1];
-		const bool cnt = (z >= 1);               // plane 0 is a Dirichlet face or counted by the lower slab
+		// plane 0 is a domain face or counted by the lower slab; with general
+		// boundaries the face plane mz is left to k_surf as well
+		const bool cnt = (z >= 1) && (!GEN || z <= g.mz - 1 || g.has_hi);
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			const long p = pb + off[e];
@@ -556,13 +573,14 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			double2 comp = {0., 0.};
 			extras(z, e, comp);
 			const bool m0 = mrow[e] && mxx, m1 = mrow[e] && mxy;
-			if (m0 && m1) {
+			const bool o0 = orow[e] && oxx, o1 = orow[e] && oxy;
+			if (o0 && o1) {
 				st2s(a.O + p, out);
 				if (KIND == KF_RES) st2s(a.O2 + p, out);
-			} else if (m0) {
+			} else if (o0) {
 				a.O[p] = out.x;
 				if (KIND == KF_RES) a.O2[p] = out.x;
-			} else if (m1) {
+			} else if (o1) {
 				a.O[p + 1] = out.y;
 				if (KIND == KF_RES) a.O2[p + 1] = out.y;
 			}
@@ -595,7 +613,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		__syncthreads();
 	}
-	if (z1 - 1 == a.zhi && g.has_hi && a.zhi == g.mz) {
+	if (z1 - 1 == a.zhi && (GEN || g.has_hi) && a.zhi == g.mz) {
 		if (KIND == KF_A1 || KIND == KF_B1L) {
 #pragma unroll
 			for (int e = 0; e < VD; ++e) { double2 d; extras(g.mz + 1, e, d); }
@@ -608,6 +626,70 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	}
 }
 
+// Boundary-plane terms of the dot products of a general-boundary fused kernel,
+// taken after the boundary treatment of its output: all points with i in {0,mx},
+// j in {0,my} or k on a z face of the domain, weighted 1/2 per boundary direction
+// (Krylov.C:180-233).  Its blocks append their partial sums to those of k_fused
+// and the last one finishes the reduction.  Item order: the z-face planes (x
+// fastest), then the y-face rows of the other counted planes, then the x-face
+// columns of their inner rows.
+template <int KIND>
+__global__ __launch_bounds__(NT) void k_surf(const KryFused a)
+{
+	constexpr int ND = KindTraits<KIND>::ND;
+	const KryGeo &g = a.g;
+	if (a.S->done) return;
+	double acc[ND];
+#pragma unroll
+	for (int k = 0; k < ND; ++k) acc[k] = 0.;
+	const long nxy = (long)(g.mx + 1) * (g.my + 1);
+	const int nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
+	const int k1 = 1, k2 = g.has_hi ? g.mz : g.mz - 1, nk = k2 - k1 + 1;
+	const long tz = nzf * nxy, ty = 2L * nk * (g.mx + 1), tx = 2L * nk * (g.my - 1);
+	const long total = tz + ty + tx;
+	for (long t = (long)blockIdx.x * NT + threadIdx.x; t < total; t += (long)gridDim.x * NT) {
+		int i, j, k;
+		bool bz = false;
+		if (t < tz) {
+			const int f = (int)(t / nxy);
+			const long rem = t - f * nxy;
+			j = (int)(rem / (g.mx + 1));
+			i = (int)(rem - (long)j * (g.mx + 1));
+			k = (f == 0 && !g.has_lo) ? 0 : g.mz;
+			bz = true;
+		} else if (t < tz + ty) {
+			const long rem = t - tz;
+			const long r2 = rem / (g.mx + 1);
+			i = (int)(rem - r2 * (g.mx + 1));
+			j = (r2 & 1) ? g.my : 0;
+			k = k1 + (int)(r2 >> 1);
+		} else {
+			const long rem = t - tz - ty;
+			const long r2 = rem / (g.my - 1);
+			j = 1 + (int)(rem - r2 * (g.my - 1));
+			i = (r2 & 1) ? g.mx : 0;
+			k = k1 + (int)(r2 >> 1);
+		}
+		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
+		const double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
+		const long p = kry_idx(g, i, j, k);
+		const double o = a.O[p];
+		if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
+			acc[0] += wgt * (o * a.RT[p]);
+		} else if (KIND == KF_B0L) {
+			acc[0] += wgt * (a.Xout[p] * o);
+			acc[ND > 1 ? 1 : 0] += wgt * (o * o);
+		} else if (KIND == KF_B1L) {
+			const double r1 = a.Xout[p];
+			acc[0] += wgt * (r1 * r1);
+			acc[ND > 1 ? 1 : 0] += wgt * (a.E[p] * r1);
+			acc[ND > 2 ? 2 : 0] += wgt * (o * r1);
+		}
+	}
+	KryRed r = a.red;
+	reduce_and_finalize<ND>(acc, r, a.blk_off);
+}
+
 // ---------------------------------------------------------------------------
 // streaming kernels of the MR part (no stencil): one block per plane segment
 // ---------------------------------------------------------------------------
@@ -616,6 +698,24 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 // (solveLin_BICGStab.C:420-428, jj = 2).  r2' is not written back: its only other
 // use is the r0 update of k_final, which recomputes it from r2 and r1 with the
 // same two roundings, and r2 is overwritten by the next pass before any other read.
+// In-plane weights of the two values of a double2 at plane offset q (counted from
+// column QOFF of row 0): 0 off the points 0..m, 1/2 per boundary direction.
+// corner[d] tells whether the value sits on an x and a y boundary.
+__device__ inline void plane_weights(const KryGeo &g, long q, double (&wxy)[2], bool (&corner)[2])
+{
+#pragma unroll
+	for (int d = 0; d < 2; ++d) {
+		const long qq = q + d + QOFF;
+		const int row = (int)(qq / g.px);
+		const int i = (int)(qq - (long)row * g.px) - 2, j = row - 1;
+		const bool in = (i >= 0 && i <= g.mx && j >= 0 && j <= g.my);
+		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
+		wxy[d] = in ? (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) : 0.;
+		corner[d] = in && bx && by;
+	}
+}
+
+template <bool GEN>
 __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 {
 	KryState *S = a.S;
@@ -624,6 +724,14 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 	const double ntau = -S->tau[1][2];
 	double acc[2] = {0., 0.};
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	double wxy[GEN ? UN : 1][2];
+	if (GEN) {
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			bool c[2];
+			plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], c);
+		}
+	}
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
@@ -640,7 +748,15 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 			const long q = q0 + 2L * i * NT;
 			if (q < a.g.ps) {
 				r2[i] = axpy2(r2[i], r1[i], ntau);   // kept in registers only: k_final recomputes it
-				if (cnt) {
+				if (GEN) {
+					if (cnt) {
+						const bool bz = (z == 0 && !a.g.has_lo) || (z == a.g.mz && !a.g.has_hi);
+						const double wz = bz ? 0.5 : 1.;
+						const double w0 = wxy[GEN ? i : 0][0] * wz, w1 = wxy[GEN ? i : 0][1] * wz;
+						acc[0] += w0 * (r2[i].x * r2[i].x); acc[0] += w1 * (r2[i].y * r2[i].y);
+						acc[1] += w0 * (r0[i].x * r2[i].x); acc[1] += w1 * (r0[i].y * r2[i].y);
+					}
+				} else if (cnt) {
 					acc[0] += r2[i].x * r2[i].x; acc[0] += r2[i].y * r2[i].y;
 					acc[1] += r0[i].x * r2[i].x; acc[1] += r0[i].y * r2[i].y;
 				}
@@ -656,7 +772,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 //   u0 -= gamma_jj*u_jj; phi += gammapp_jj*r_jj; r0 -= gammap_jj*r_jj;
 //   dots |r0|^2 and (r0, r~).
 // v[0..L] = r0..rL, v[L+1..2L+1] = u0..uL, v[2L+2] = r~, w[0] = phi, w[1] = r0, w[2] = u0.
-template <int L>
+template <int L, bool GEN>
 __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 {
 	KryState *S = a.S;
@@ -669,6 +785,12 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 	constexpr int UN = SEG2 / NT;
 	double acc[2] = {0., 0.};
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	double wxy[GEN ? UN : 1][2];
+	bool wcorner[GEN ? UN : 1][2];
+	if (GEN) {
+#pragma unroll
+		for (int i = 0; i < UN; ++i) plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], wcorner[GEN ? i : 0]);
+	}
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
@@ -702,7 +824,19 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 				st2s(a.w[0] + p, phv);
 				st2s(a.w[1] + p, r0);
 				st2s(a.w[2] + p, u0);
-				if (cnt) {
+				if (GEN) {
+					if (cnt) {
+						// |r0|^2 with the norm's weights (corners 1/4, Krylov.C:136-143),
+						// (r0, r~) with the dot product's (corners 1/8, Krylov.C:226-233)
+						const bool bz = (z == 0 && !a.g.has_lo) || (z == a.g.mz && !a.g.has_hi);
+						const double wz = bz ? 0.5 : 1.;
+						const double w0 = wxy[GEN ? i : 0][0] * wz, w1 = wxy[GEN ? i : 0][1] * wz;
+						const double n0 = (bz && wcorner[GEN ? i : 0][0]) ? 0.25 : w0;
+						const double n1 = (bz && wcorner[GEN ? i : 0][1]) ? 0.25 : w1;
+						acc[0] += n0 * (r0.x * r0.x);   acc[0] += n1 * (r0.y * r0.y);
+						acc[1] += w0 * (r0.x * rt[i].x); acc[1] += w1 * (r0.y * rt[i].y);
+					}
+				} else if (cnt) {
 					acc[0] += r0.x * r0.x;   acc[0] += r0.y * r0.y;
 					acc[1] += r0.x * rt[i].x; acc[1] += r0.y * rt[i].y;
 				}
@@ -863,11 +997,49 @@ template <int KIND, int TY>
 static hipError_t launch_fused_t(const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
 {
 	dim3 grid(a.nblk), block(NT);
-#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, TY, V, O, E>), grid, block, 0, st, a)
+#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, TY, V, O, E, false>), grid, block, 0, st, a)
 	if (!var) KRY_LAUNCH(false, false, true);
 	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
 	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
 #undef KRY_LAUNCH
+	return hipGetLastError();
+}
+
+// general-boundary variants: field coefficients only, 8-row tiles
+template <int KIND>
+static hipError_t launch_fused_gen_t(const KryFused &a, bool offd, bool exact, hipStream_t st)
+{
+	dim3 grid(a.nblk), block(NT);
+#define KRY_LAUNCH(O, E) hipLaunchKernelGGL((k_fused<KIND, 8, true, O, E, true>), grid, block, 0, st, a)
+	if (!offd) { if (exact) KRY_LAUNCH(false, true); else KRY_LAUNCH(false, false); }
+	else { if (exact) KRY_LAUNCH(true, true); else KRY_LAUNCH(true, false); }
+#undef KRY_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool offd, bool exact, hipStream_t st)
+{
+	switch (kind) {
+	case KF_A0:  return launch_fused_gen_t<KF_A0>(a, offd, exact, st);
+	case KF_A1:  return launch_fused_gen_t<KF_A1>(a, offd, exact, st);
+	case KF_B0:  return launch_fused_gen_t<KF_B0>(a, offd, exact, st);
+	case KF_B0L: return launch_fused_gen_t<KF_B0L>(a, offd, exact, st);
+	case KF_B1L: return launch_fused_gen_t<KF_B1L>(a, offd, exact, st);
+	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st)
+{
+	dim3 grid(nblk), block(NT);
+	switch (kind) {
+	case KF_A0:  hipLaunchKernelGGL(k_surf<KF_A0>, grid, block, 0, st, a); break;
+	case KF_A1:  hipLaunchKernelGGL(k_surf<KF_A1>, grid, block, 0, st, a); break;
+	case KF_B0:  hipLaunchKernelGGL(k_surf<KF_B0>, grid, block, 0, st, a); break;
+	case KF_B0L: hipLaunchKernelGGL(k_surf<KF_B0L>, grid, block, 0, st, a); break;
+	case KF_B1L: hipLaunchKernelGGL(k_surf<KF_B1L>, grid, block, 0, st, a); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 
@@ -892,14 +1064,17 @@ hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool 
 
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_mgs2, dim3(nbx, nby), dim3(NT), 0, st, a);
+	if (a.gen) hipLaunchKernelGGL(k_mgs2<true>, dim3(nbx, nby), dim3(NT), 0, st, a);
+	else hipLaunchKernelGGL(k_mgs2<false>, dim3(nbx, nby), dim3(NT), 0, st, a);
 	return hipGetLastError();
 }
 
 hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st)
 {
-	if (L == 1) hipLaunchKernelGGL(k_final<1>, dim3(nbx, nby), dim3(NT), 0, st, a);
-	else if (L == 2) hipLaunchKernelGGL(k_final<2>, dim3(nbx, nby), dim3(NT), 0, st, a);
+	if (L == 1 && !a.gen) hipLaunchKernelGGL((k_final<1, false>), dim3(nbx, nby), dim3(NT), 0, st, a);
+	else if (L == 2 && !a.gen) hipLaunchKernelGGL((k_final<2, false>), dim3(nbx, nby), dim3(NT), 0, st, a);
+	else if (L == 1) hipLaunchKernelGGL((k_final<1, true>), dim3(nbx, nby), dim3(NT), 0, st, a);
+	else if (L == 2) hipLaunchKernelGGL((k_final<2, true>), dim3(nbx, nby), dim3(NT), 0, st, a);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }

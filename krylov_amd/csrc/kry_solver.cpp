@@ -95,7 +95,8 @@ struct kry_solver {
 	kry_desc d;
 	int L = 1;
 	int mzl = 0;               // slab-local mz
-	bool fused = false;        // fused Dirichlet path in use
+	bool fused = false;        // fused path in use (device-resident recurrences)
+	bool gen = false;          // its general-boundary variant (any face types, field coefficients)
 	bool var = false, offd = false;
 	bool loaded = false;
 	KryOp op;
@@ -383,10 +384,17 @@ struct Tiling {
 Tiling tiling(const kry_solver *h, const Slab &s)
 {
 	Tiling t;
-	t.ntx = (s.g.mx + KRY_TXW - 1) / KRY_TXW;       // columns i = 0 .. mx-1
-	t.nty = (s.g.my + h->ty - 1) / h->ty;             // rows    j = 0 .. my-1
-	t.zlo = s.g.has_lo ? 0 : 1;
-	t.zhi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
+	if (h->gen) {
+		t.ntx = (s.g.mx + 4 + KRY_TXW - 1) / KRY_TXW;   // columns 0 .. mx+3 (i = -2 .. mx+1)
+		t.nty = (s.g.my + 3 + 8 - 1) / 8;                // rows    j = -1 .. my+1
+		t.zlo = 0;
+		t.zhi = s.g.mz;
+	} else {
+		t.ntx = (s.g.mx + KRY_TXW - 1) / KRY_TXW;       // columns i = 0 .. mx-1
+		t.nty = (s.g.my + h->ty - 1) / h->ty;             // rows    j = 0 .. my-1
+		t.zlo = s.g.has_lo ? 0 : 1;
+		t.zhi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
+	}
 	const int nz = t.zhi - t.zlo + 1;
 	t.nchunk = (nz + h->zc - 1) / h->zc;
 	t.nblk = t.ntx * t.nty * t.nchunk;
@@ -419,9 +427,20 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 {
 	HIPCHK(hipSetDevice(s.device));
 	if (prof & 1) prof_begin(h, s, kind);
-	HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
+	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->offd, h->op.exact_rcp != 0, s.st));
+	else HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 	if (prof & 2) prof_end(h, s);
 	return 0;
+}
+
+// blocks of the boundary-plane dot kernel that follows a general-boundary stencil kernel
+int surf_blocks(const KryGeo &g)
+{
+	const long nxy = (long)(g.mx + 1) * (g.my + 1);
+	const int nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
+	const int nk = (g.has_hi ? g.mz : g.mz - 1);
+	const long total = nzf * nxy + 2L * nk * (g.mx + 1) + 2L * nk * (g.my - 1);
+	return (int)std::max<long>(1, std::min<long>((total + 255) / 256, KRY_SURF_BLOCKS));
 }
 
 KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby, int min_planes)
@@ -431,12 +450,14 @@ KryStream stream_base(kry_solver *h, Slab &s, int phase, int *nbx, int *nby, int
 	a.g = s.g;
 	a.S = s.S;
 	// planes touched: every plane whose values this slab must keep current
-	const int zf = s.g.has_lo ? -1 : 1;
-	const int zl = s.g.has_hi ? s.g.mz + 1 : s.g.mz - 1;
+	// (with general boundaries the ghost planes are live data too)
+	const int zf = (h->gen || s.g.has_lo) ? -1 : 1;
+	const int zl = (h->gen || s.g.has_hi) ? s.g.mz + 1 : s.g.mz - 1;
 	a.zfirst = zf;
 	a.nplanes = zl - zf + 1;
-	a.cnt_lo = 1;
-	a.cnt_hi = s.g.has_hi ? s.g.mz : s.g.mz - 1;
+	a.cnt_lo = (h->gen && !s.g.has_lo) ? 0 : 1;
+	a.cnt_hi = (h->gen || s.g.has_hi) ? s.g.mz : s.g.mz - 1;
+	a.gen = h->gen ? 1 : 0;
 	// segments of a plane in x, groups of planes in y
 	*nbx = (int)((s.g.ps + KRY_SEG - 1) / KRY_SEG);
 	// min_planes per block: the read-only kernel amortises its end-of-block reduction
@@ -460,6 +481,23 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 	for (int i = 0; i < ns; ++i) {
 		args[i] = make_args(h->slabs[i]);
 		outs[i] = args[i].O;
+	}
+	if (h->gen) {
+		// stencil on all points, then the boundary treatment of its output
+		// (Krylov.C:493-495), then the boundary-plane terms of the dots
+		for (int i = 0; i < ns; ++i) {
+			Slab &s = h->slabs[i];
+			KryFused a = args[i];
+			const int nsurf = surf_blocks(s.g);
+			a.red.nblk = a.nblk + nsurf;
+			CHK(launch_fused(h, s, kind, a, 1));
+			HIPCHK(kry_launch_bcs(a.O, s.g, s.st));
+			a.blk_off = a.nblk;
+			HIPCHK(kry_launch_surf(kind, a, nsurf, s.st));
+			prof_end(h, s);
+		}
+		if (multi) CHK(exchange_halo(h, outs));
+		return 0;
 	}
 	// the neighbours need planes 1 and mz-1: chunk 0 and the chunk holding plane mz-1
 	// (the last one, or the one before it when the last chunk is plane mz alone)
@@ -873,7 +911,45 @@ int prologue(kry_solver *h)
 	h->norm_rhs = std::sqrt(ss);
 	if (h->norm_rhs == 0.) h->norm_rhs = 1.;
 
-	if (h->fused) {
+	if (h->fused && h->gen) {
+		// residual, its norm and (r0, r~) with the one-kernel-per-primitive path, then
+		// the head of the first pass on the host (:301-320, :341, :349-352 with jj = 0)
+		CHK(g_residual(h));
+		auto r0 = ptrs_r(h, 0), rt = ptrs(h, &Slab::rt);
+		double rho1;
+		CHK(g_dot(h, r0, r0, 1, &ss));
+		CHK(g_dot(h, r0, r0, 0, &rho1));
+		KryState init;
+		memset(&init, 0, offsetof(KryState, hist));
+		init.eps = h->d.eps;
+		init.norm_rhs = h->norm_rhs;
+		init.max_outer = h->d.max_outer;
+		init.L = h->L;
+		init.local_scalars = (h->slabs.size() == 1 && !h->comm.active()) ? 1 : 0;
+		init.norm_init = std::sqrt(ss);
+		init.norm = 1.e99;
+		if (init.norm_init < h->d.eps * h->norm_rhs) {
+			init.norm = init.norm_init;
+			init.done = 1;
+		} else {
+			double rho0 = 1., alpha = 0., omega = 1.;
+			rho0 = rho0 * (-omega);
+			init.beta = alpha * rho1 / rho0;
+			init.rho0 = rho1;
+			init.rho1 = rho1;
+			init.alpha = alpha;
+			init.omega = omega;
+		}
+		for (size_t i = 0; i < h->slabs.size(); ++i) {
+			Slab &s = h->slabs[i];
+			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(hipMemcpyAsync(rt[i], r0[i], (size_t)s.g.n * sizeof(double), hipMemcpyDeviceToDevice, s.st));
+			memcpy(s.Sh, &init, offsetof(KryState, hist));
+			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
+			HIPCHK(hipStreamSynchronize(s.st));
+		}
+		CHK(poll_state(h));
+	} else if (h->fused) {
 		for (Slab &s : h->slabs) {
 			HIPCHK(hipSetDevice(s.device));
 			KryState init;
@@ -998,7 +1074,13 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	make_op(h, var, Dc);
 	bool dirichlet = true;
 	for (int f = 0; f < 6; ++f) dirichlet = dirichlet && (h->d.bc_type[f] == 0);
-	h->fused = dirichlet && h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
+	// Dirichlet faces: fused kernels that keep the zero boundary implicit.  Other
+	// face types: their general-boundary variant, for field coefficients only (the
+	// constant-coefficient operator re-applies the boundary treatment to its INPUT,
+	// Krylov.C:516, which cannot be folded into the producing update).
+	const bool can_fuse = h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
+	h->gen = can_fuse && !dirichlet && var;
+	h->fused = can_fuse && (dirichlet || h->gen);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
 	if (h->slabs.size() > 1 || h->comm.active()) {
 		// interface ghosts of the inputs, as solve_int does under `parallel`
@@ -1302,7 +1384,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	memset(o, 0, sizeof *o);
 	o->status = h->status;
 	o->iterations = h->it_base;
-	o->fused = h->fused ? 1 : 0;
+	o->fused = h->fused ? (h->gen ? 2 : 1) : 0;
 	o->norm_rhs = h->norm_rhs;
 	o->norm_init = h->norm_init;
 	o->norm_final = h->norm_final;
@@ -1317,7 +1399,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	const double npts = (double)(h->d.mx[0] + 1) * (h->d.mx[1] + 1) * ((double)h->mzl * h->d.nslabs + 1);
 	o->bytes_per_iter = 8.0 * W * npts;
 	for (int k = 0; k < 8; ++k) { o->kernel_ms[k] = h->kernel_ms[k]; o->kernel_calls[k] = h->kernel_calls[k]; }
-	o->tile_rows = h->ty;
+	o->tile_rows = h->gen ? 8 : h->ty;
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;
 	return 0;
@@ -1349,6 +1431,7 @@ int kry_get_history(kry_handle h, double *norms, int cap)
 
 static int op_prepare(kry_handle h, bool var, bool offd, const double Dc[3])
 {
+	h->gen = false;
 	h->var = var;
 	h->offd = var && offd;
 	make_op(h, var, Dc);

@@ -14,10 +14,11 @@
  *   per wave     shuffle tree: v[i] += v[i+o], o = 32,16,8,4,2,1
  *   per block    wave sums added in wave order
  *   grid         thread t adds partials t, t+256, ...; then wave tree; then waves
- * Three kernel shapes exist: the fused stencil kernels (tiles of 128 x ty points
- * marched over zc planes, XCD-swizzled block order), the streaming kernels
- * (2048-double plane segments x plane groups) and the generic weighted dot (one
- * block per 256 points of a grid row).
+ * Kernel shapes: the fused stencil kernels (tiles of 128 x ty points marched over
+ * zc planes, XCD-swizzled block order; the general-boundary variant shifts the
+ * tiles onto the ghost-inclusive box and is followed by a boundary-plane kernel),
+ * the streaming kernels (2048-double plane segments x plane groups) and the
+ * generic weighted dot (waves walking grid rows).
  */
 #include "krylov_oracle.h"
 
@@ -27,7 +28,7 @@
 #define NT 256
 #define NW 4
 
-static int g_mode = 0;          /* 0 off, 1 fused path, 2 generic path */
+static int g_mode = 0;          /* 0 off, 1 fused Dirichlet path, 2 generic path, 3 fused general-boundary path */
 static int g_ty = 8, g_zc = 16, g_sb = 2048;
 
 typedef struct { int mx, my, mz; long sx, sy; } hbox;
@@ -146,6 +147,131 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B, int
 	return v;
 }
 
+/* ---- general-boundary fused path ---- */
+
+static double face_weight(const hbox *b, int i, int j, int k)
+{
+	const int fx = (i == 0 || i == b->mx), fy = (j == 0 || j == b->my), fz = (k == 0 || k == b->mz);
+	return (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
+}
+
+/* k_fused<GEN> (tiles start at column 0 and row j = -1, planes 0..mz, strict interior
+ * counted) followed by k_surf (boundary planes, weighted), one reduction over both */
+static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
+{
+	const hbox b = hb(c);
+	const int ty = 8, zc = g_zc, VD = ty / NW;
+	const int ntx = (b.mx + 4 + 127) / 128, nty = (b.my + 3 + ty - 1) / ty;
+	const int zlo = 0, zhi = b.mz;
+	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
+	const long nf = (long)ntx * nty * nchunk;
+	const long nxy = (long)(b.mx + 1) * (b.my + 1);
+	const int k1 = 1, nk = b.mz - 1;
+	const long tz = 2 * nxy, tyy = 2L * nk * (b.mx + 1), txx = 2L * nk * (b.my - 1), total = tz + tyy + txx;
+	long ns = (total + 255) / 256;
+	if (ns > 512) ns = 512;
+	if (ns < 1) ns = 1;
+	double *partial = (double *)malloc((size_t)(nf + ns) * sizeof(double));
+	for (long bp = 0; bp < nf; ++bp) {
+		const long q = nf >> 3, r = nf & 7, x = bp & 7;
+		const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
+		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
+		const int z0 = zlo + ch * zc;
+		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
+		const int y0 = tyi * ty - 1;
+		double acc[NT];
+		for (int t = 0; t < NT; ++t) {
+			const int w = t >> 6, lane = t & 63;
+			const int i0 = 128 * tx + 2 * lane - 2;
+			double s = 0.;
+			for (int z = z0; z < z1; ++z)
+				for (int e = 0; e < VD; ++e) {
+					const int j = y0 + w * VD + e;
+					if (j < 1 || j > b.my - 1 || z < 1 || z > b.mz - 1) continue;
+					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, z) * HAT(b, B, i0, j, z);
+					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, z) * HAT(b, B, i0 + 1, j, z);
+				}
+			acc[t] = s;
+		}
+		partial[bp] = block_total(acc);
+	}
+	for (long blk = 0; blk < ns; ++blk) {
+		double acc[NT];
+		for (int t0 = 0; t0 < NT; ++t0) {
+			double s = 0.;
+			for (long t = blk * NT + t0; t < total; t += ns * NT) {
+				int i, j, k;
+				if (t < tz) {
+					const int f = (int)(t / nxy);
+					const long rem = t - f * nxy;
+					j = (int)(rem / (b.mx + 1));
+					i = (int)(rem - (long)j * (b.mx + 1));
+					k = f ? b.mz : 0;
+				} else if (t < tz + tyy) {
+					const long rem = t - tz, r2 = rem / (b.mx + 1);
+					i = (int)(rem - r2 * (b.mx + 1));
+					j = (r2 & 1) ? b.my : 0;
+					k = k1 + (int)(r2 >> 1);
+				} else {
+					const long rem = t - tz - tyy, r2 = rem / (b.my - 1);
+					j = 1 + (int)(rem - r2 * (b.my - 1));
+					i = (r2 & 1) ? b.mx : 0;
+					k = k1 + (int)(r2 >> 1);
+				}
+				s += face_weight(&b, i, j, k) * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
+			}
+			acc[t0] = s;
+		}
+		partial[nf + blk] = block_total(acc);
+	}
+	double v = grid_total(partial, nf + ns);
+	free(partial);
+	return v;
+}
+
+/* k_final<GEN>, k_mgs2<GEN>: planes -1..mz+1, weighted points */
+static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B, int min_planes, int norm_mode)
+{
+	const hbox b = hb(c);
+	const long px = ((b.mx + 4 + 15) / 16) * 16, ps = px * (b.my + 3);
+	const int nbx = (int)((ps + 2047) / 2048);
+	const int nplanes = b.mz + 3;
+	int nby = (g_sb + nbx - 1) / nbx;
+	const int cap = nplanes / min_planes > 1 ? nplanes / min_planes : 1;
+	if (nby > cap) nby = cap;
+	if (nby < 1) nby = 1;
+	const long nblk = (long)nbx * nby;
+	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
+	for (int by = 0; by < nby; ++by)
+		for (int bx = 0; bx < nbx; ++bx) {
+			double acc[NT];
+			for (int t = 0; t < NT; ++t) {
+				double s = 0.;
+				for (int pl = by; pl < nplanes; pl += nby) {
+					const int z = -1 + pl;
+					if (z < 0 || z > b.mz) continue;
+					for (int i = 0; i < 4; ++i) {
+						const long q = 2 * ((long)bx * 1024 + i * NT + t);
+						if (q >= ps) break;
+						for (int d = 0; d < 2; ++d) {
+							const long qq = q + d + 2;
+							const int jj = (int)(qq / px) - 1, ii = (int)(qq % px) - 2;
+							if (ii < 0 || ii > b.mx || jj < 0 || jj > b.my) continue;
+							double wgt = face_weight(&b, ii, jj, z);
+							if (norm_mode && wgt == 0.125) wgt = 0.25;
+							s += wgt * (HAT(b, A, ii, jj, z) * HAT(b, B, ii, jj, z));
+						}
+					}
+				}
+				acc[t] = s;
+			}
+			partial[bx + (long)nbx * by] = block_total(acc);
+		}
+	double v = grid_total(partial, nblk);
+	free(partial);
+	return v;
+}
+
 /* generic weighted dot: g_wdot (wave w of block b walks grid rows 4b+w, +4*nblk, ...;
  * a lane takes points lane, lane+64, ... of each row) */
 static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int norm_mode)
@@ -186,6 +312,21 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 		if (site == ORC_SITE_NORM_RHS || site == ORC_SITE_NORM_INIT || site == ORC_SITE_NORM)
 			return sqrt(wdot_sum(c, a, b, 1));
 		return wdot_sum(c, a, b, 0);
+	}
+	if (g_mode == 3) {   /* general-boundary fused path */
+		switch (site) {
+		case ORC_SITE_NORM_RHS:
+		case ORC_SITE_NORM_INIT: return sqrt(wdot_sum(c, a, b, 1));
+		case ORC_SITE_RHO:
+			if (jj == 0) return iter == 1 ? wdot_sum(c, a, b, 0) : stream_gen_sum(c, a, b, 1, 0);
+			return fused_gen_sum(c, a, b);
+		case ORC_SITE_ALPHA:
+		case ORC_SITE_TAU:       return fused_gen_sum(c, a, b);
+		case ORC_SITE_SIGMA:
+		case ORC_SITE_GAMMAP:    return jj == 1 ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
+		case ORC_SITE_NORM:      return sqrt(stream_gen_sum(c, a, b, 1, 1));
+		}
+		return orc_dot(c, a, b);
 	}
 	switch (site) {
 	case ORC_SITE_NORM_RHS:  return sqrt(wdot_sum(c, a, b, 1));

@@ -154,8 +154,9 @@ def l2norm(cfg, v):
 
 
 def use_gpu_order(mode, ty=8, zc=16, stream_blocks=2048):
-    """mode 0: reference summation order; 1: order of the fused device path;
-    2: order of the generic device path (see gpu_order.c)."""
+    """mode 0: reference summation order; 1: order of the fused Dirichlet device
+    path; 2: order of the generic device path; 3: order of the fused
+    general-boundary device path (see gpu_order.c)."""
     lib().orc_use_gpu_order(int(mode), int(ty), int(zc), int(stream_blocks))
 
 

@@ -46,7 +46,7 @@ def make(kind, n):
 def run_pair(orc, p, L, eps, max_outer, flags=0):
     got = capi.solve_problem(p, L=L, eps=eps, max_outer=max_outer, flags=flags)
     ty, zc, sb = got["order"]
-    orc.use_gpu_order(1 if got["fused"] else 2, ty, zc, sb)
+    orc.use_gpu_order({0: 2, 1: 1, 2: 3}[got["path"]], ty, zc, sb)
     try:
         want = oracle_solve(orc, p, L=L, eps=eps, max_outer=max_outer)
     finally:
@@ -92,6 +92,46 @@ def test_generic_path_matches_oracle_in_device_order(orc, bc, L):
     want, got = run_pair(orc, p, L, eps=1e-13, max_outer=50, flags=capi.KRY_FORCE_GENERIC)
     assert not got["fused"]
     assert_identical(want, got, min_passes=50 // L if L > 2 else 50)
+
+
+MIXED = [(0, 0, 1, 1, 0, 1), (1, 0, 0, 1, 1, 0), (1, 1, 1, 1, 1, 1), (0, 0, 0, 0, 1, 1), (0, 1, 0, 0, 0, 0)]
+
+
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("bc", MIXED)
+def test_general_boundary_fused_path_matches_oracle_in_device_order(orc, bc, L):
+    """Extrapolating / mixed faces with field coefficients run the fused kernels'
+    general-boundary variant (vector updates on ghost cells, boundary treatment
+    and boundary-plane dot terms after each stencil kernel)."""
+    p = P.smooth_var(24, bc=bc)
+    p.rhs = np.random.default_rng(3).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=50)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=50)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9)])
+def test_general_boundary_fused_path_ragged_shapes(orc, n, L):
+    """Tile edges that fall inside the ghost layer, several tiles per row, short chunks."""
+    bc = (1, 1, 0, 1, 1, 1)
+    p = P.smooth_var(n, bc=bc)
+    p.rhs = np.random.default_rng(5).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=30)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=30)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_general_boundary_fused_path_with_offdiagonal_term(orc, L):
+    """The 11-point operator reads edge ghosts, which only the whole-array update
+    semantics and the face order of do_BCs define."""
+    p = P.offdiag_var(24)
+    p.bc = (1, 0, 1, 1, 0, 1)
+    p.rhs = np.random.default_rng(8).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=30)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=30)
 
 
 def test_summation_order_alone_moves_the_history(orc):

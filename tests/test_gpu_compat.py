@@ -48,11 +48,19 @@ def test_adaptor_class_equals_c_abi(maker, L):
     assert np.array_equal(a["phi"], b["phi"])
 
 
-def test_adaptor_mixed_faces_uses_generic_kernels():
+def test_adaptor_mixed_faces():
+    """Field coefficients with extrapolating faces: the fused general-boundary
+    kernels; constant coefficients: one kernel per primitive."""
     p = P.smooth_var(16, bc=(0, 0, 1, 1, 0, 1))
     a = adaptor_solve(p, 2, 1e-6)
     b = capi.solve_problem(p, L=2, eps=1e-6)
-    assert not a["fused"]
+    assert a["fused"] and b["path"] == 2
+    assert np.array_equal(a["history"], b["history"])
+    q = P.reference_test1(16)
+    q.bc = (0, 0, 1, 1, 0, 1)
+    a = adaptor_solve(q, 2, 1e-6)
+    b = capi.solve_problem(q, L=2, eps=1e-6)
+    assert not a["fused"] and b["path"] == 0
     assert np.array_equal(a["history"], b["history"])
 
 

@@ -72,13 +72,17 @@ def test_full_solve_on_slabs(orc, nslabs):
 
 
 @pytest.mark.parametrize("nslabs", [2, 4])
-@pytest.mark.parametrize("L", [1, 2, 3])
-def test_generic_path_on_slabs_mixed_faces(orc, nslabs, L):
-    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
-    p.mx = (24, 24, 24)
+@pytest.mark.parametrize("L,flags,path", [(1, 0, 2), (2, 0, 2), (1, capi.KRY_FORCE_GENERIC, 0),
+                                          (2, capi.KRY_FORCE_GENERIC, 0), (3, 0, 0)])
+@pytest.mark.parametrize("bc", [(0, 0, 1, 1, 0, 1), (1, 1, 0, 1, 1, 1)])
+def test_mixed_faces_on_slabs(orc, bc, nslabs, L, flags, path):
+    """Extrapolating faces across slabs: the fused general-boundary kernels (l <= 2)
+    and the one-kernel-per-primitive path."""
+    p = P.smooth_var(24, bc=bc)
+    p.rhs = np.random.default_rng(9).uniform(-1, 1, p.rhs.shape)
     want = oracle_solve(orc, p, L=L, eps=1e-30, max_outer=3)
-    got = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, nslabs_local=nslabs, devices=(0,))
-    assert not got["fused"]
+    got = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, nslabs_local=nslabs, devices=(0,), flags=flags)
+    assert got["path"] == path
     assert got["iters"] == 3
     assert np.max(np.abs(got["history"] - want["history"])) <= 1e-10 * want["norm_rhs"]
     assert rel_l2(points(got["phi"]), points(want["phi"])) <= 1e-10
@@ -99,6 +103,17 @@ def test_split_launch_with_overlapped_exchange(orc, monkeypatch, L, overlap, nsl
     assert one["fused"] and many["fused"] and many["iters"] == 6
     assert np.max(np.abs(one["history"] - many["history"])) <= 1e-10 * one["norm_rhs"]
     assert rel_l2(points(many["phi"]), points(one["phi"])) <= 1e-10
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_mixed_faces_on_slabs_longer_run(orc, L):
+    """Twelve passes on 1, 2 and 4 slabs stay together to rounding noise."""
+    p = P.smooth_var((40, 24, 32), bc=(0, 1, 1, 0, 1, 1))
+    p.rhs = np.random.default_rng(10).uniform(-1, 1, p.rhs.shape)
+    runs = [capi.solve_problem(p, L=L, eps=1e-30, max_outer=12, nslabs_local=ns, devices=(0,)) for ns in (1, 2, 4)]
+    assert all(r["path"] == 2 and r["iters"] == 12 for r in runs)
+    for r in runs[1:]:
+        assert np.max(np.abs(r["history"][:6] - runs[0]["history"][:6])) <= 1e-9 * runs[0]["norm_rhs"]
 
 
 def test_repeated_multi_slab_solves_are_reproducible(orc):

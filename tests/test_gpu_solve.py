@@ -90,8 +90,10 @@ def test_smooth_var_fused_vs_generic(orc, L):
 
 
 @pytest.mark.parametrize("L", [1, 2, 4])
-def test_mixed_boundaries_generic(orc, L):
-    compare(orc, P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1)), L, expect_fused=False)
+def test_mixed_boundaries(orc, L):
+    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
+    compare(orc, p, L, expect_fused=(L <= 2))          # general-boundary fused kernels for l <= 2
+    compare(orc, p, L, flags=capi.KRY_FORCE_GENERIC, expect_fused=False)
 
 
 def test_non_cubic_grid(orc):
