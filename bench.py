@@ -54,6 +54,8 @@ def measured_traffic(kernel_name, n, L, workload, world):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes
     (profiles/*_hbm_traffic.json), if they were taken on this very workload."""
     import glob
+    if workload == "mixed":
+        return None, None
     want = "%d^3 fp64 %s-coefficient, l=%d, %d GPU" % (n, "variable" if workload == "var" else "constant", L, world)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
         try:
@@ -82,7 +84,19 @@ def slab_problem(n, nslabs, slab, workload, nz=None):
     f = {}
     f["lam"] = full(0.2 * x * (y * y) * z)
     sinx, siny, sinz = np.sin(pi * x), np.sin(pi * y), np.sin(pi * z)
-    if workload == "var":
+    f["bc"] = (0,) * 6
+    if workload == "mixed":
+        # anisotropic high-contrast coefficients (contrast 1e4, anisotropy 100) with mixed
+        # faces: x Dirichlet, y extrapolating, z low Dirichlet, z high extrapolating
+        e = 10.0 ** (2.0 * np.sin(2 * pi * x) * np.sin(2 * pi * y) * np.sin(2 * pi * z))
+        f["Dxx"] = full(e)
+        f["Dyy"] = full(0.1 * e)
+        f["Dzz"] = full(10.0 * e)
+        f["lam"] = np.full(shape, 1e-3)
+        f["rhs"] = full(sinx * siny * sinz)
+        f["Dc"] = (1., 1., 1.)
+        f["bc"] = (0, 0, 1, 1, 0, 1)
+    elif workload == "var":
         f["Dxx"] = full(1.0 + 0.5 * np.sin(2 * pi * x) * np.cos(2 * pi * y))
         f["Dyy"] = full(1.0 + 0.5 * np.sin(2 * pi * y) * np.cos(2 * pi * z))
         f["Dzz"] = full(1.0 + 0.5 * np.sin(2 * pi * z) * np.cos(2 * pi * x))
@@ -110,8 +124,8 @@ def _cpu_run(n_sample, L, workload, n_full, budget_iters, threads):
         "orc.build()\n"
         "%s\n"
         "f = bench.slab_problem(%d, 1, 0, %r)\n"
-        "var = %r == 'var'\n"
-        "cfg = orc.make_cfg(f['mx'], f['delx'], (0,) * 6, L=%d, eps=0.0, max_outer=%d, var_coef=var, "
+        "var = %r != 'const'\n"
+        "cfg = orc.make_cfg(f['mx'], f['delx'], f['bc'], L=%d, eps=0.0, max_outer=%d, var_coef=var, "
         "use_offdiag=False, Dc=f['Dc'])\n"
         "phi = f['phi'].copy()\n"
         "z = np.zeros_like(phi) if var else None\n"
@@ -159,7 +173,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=512, help="grid size (points 0..n per direction)")
     ap.add_argument("--ell", dest="L", type=int, default=2, help="BiCGStab(l) degree; the reference drivers use 2")
-    ap.add_argument("--workload", choices=["var", "const"], default="var")
+    ap.add_argument("--workload", choices=["var", "const", "mixed"], default="var",
+                    help="var: smooth field coefficients; const: constant coefficients (both with Dirichlet faces); "
+                         "mixed: high-contrast anisotropic field coefficients with mixed face types")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: a GRID x GRID x 128 block per GPU (GRID = 1024 gives the 1024^3 problem on 8 GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -189,14 +205,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
 
-    n, L, var = args.n, args.L, args.workload == "var"
+    n, L, var = args.n, args.L, args.workload != "const"
     nz = 128 * world if args.weak else n
     if nz % world != 0:
         sys.exit("grid size %d is not divisible by %d slabs" % (nz, world))
     f = slab_problem(n, world, rank, args.workload, nz)
 
     device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank))
-    solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
+    solver = capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, nslabs=world,
                          slab_begin=rank, slab_count=1, devices=(device,))
     transport = "none"
     if world > 1:
@@ -216,7 +232,7 @@ def main():
             from krylov_amd import gloo_transport
             transport = "gloo-staged (RCCL unavailable)"
             solver.close()
-            solver = capi.Solver(f["mx"], f["delx"], (0,) * 6, L=L, eps=0.0, max_outer=0, nslabs=world,
+            solver = capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, nslabs=world,
                                  slab_begin=rank, slab_count=1, devices=(device,))
             solver.comm_init_callbacks(rank, world, *gloo_transport.make(rank, world))
 
@@ -282,12 +298,14 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), Dirichlet faces, "
+            "config": {"workload": "%s fp64 %s-coefficient 3D stencil, BiCGStab(l=%d), %s faces, "
                                    "%d z-slab(s)" % ("%d^3" % n if nz == n else "%dx%dx%d" % (n, n, nz),
-                                                     "variable" if var else "constant", L, world),
+                                                     "variable" if var else "constant", L,
+                                                     "mixed Dirichlet/extrapolating" if args.workload == "mixed"
+                                                     else "Dirichlet", world),
                        "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world,
                        "transport": transport},
-            "valid": bool(ok),
+            "valid": bool(ok), "solver_path": s1.fused,
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),
             "iteration_words_per_point": W,

@@ -73,7 +73,7 @@ hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st);
 hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, hipStream_t st);
 hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
-hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st);
+hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,
                             const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
                             const double *Dxy, double *out, hipStream_t st);

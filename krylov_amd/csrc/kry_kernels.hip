@@ -325,12 +325,16 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // planes.  psi of plane z lives in LDS buffer z&1 (tile + one halo ring), psi of
 // planes z-1, z, z+1 at the thread's own points lives in registers.
 //
-// GEN (general boundaries): the tiles cover the ghost-inclusive box in x and y
-// (first tile column 0, first tile row j = -1) and the planes -1 .. mz+1, because
-// the reference's whole-array vector updates (solveLin_BICGStab.C:356-362,
-// 392-394) act on ghost cells too and a later stencil reads them.  The operator
-// is evaluated on every point 0..m (Krylov.C:429-459); its boundary treatment
-// and the boundary-plane terms of the dot products follow in g_bc and k_surf.
+// GEN (general boundaries, every face of type 0 or 1): the vector updates also
+// cover the ghost cells, because the reference's whole-array updates
+// (solveLin_BICGStab.C:356-362, 392-394) act on them and a later stencil reads
+// them.  Rows j = -1 .. my+1 and planes -1 .. mz+1 are tiled like the others; in
+// x the tiles stay on the aligned columns i = 0 .. and the lanes that fetch the
+// halo columns also update i = -1 (first tile) and i = mx, mx+1 (last tile).  The
+// operator is evaluated on the points 0 .. mx-1 (Krylov.C:429-459; its value at
+// i = mx is overwritten by either face type before anything reads it,
+// BoundaryHandler.C:444-460); its boundary treatment and the boundary-plane terms
+// of the dot products follow in g_bc and k_surf.
 template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN>
 __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 {
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int z0 = a.zlo + ch * a.zc;
 	const int z1 = min(z0 + a.zc, a.zhi + 1);   // exclusive
 	const int y0 = ty * TY - (GEN ? 1 : 0);     // first row (grid index j) of the tile
-	const int c0 = (GEN ? 0 : 2) + tx * TXW;    // first column of the tile
+	const int c0 = 2 + tx * TXW;                // first column of the tile
 	const int col = c0 + 2 * lane;              // column of .x ; grid index i = col - 2
 	const int ix = col - 2;
 	// strict interior: the points that count in the dot products here
@@ -396,11 +400,16 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int hr = tid >> 6;                                    // 0: row -1, 1: row TY
 	const long hoff = (long)(y0 + (hr ? TY : -1) + 1) * g.px + col;
 	const int hl = (hr ? TY + 1 : 0) * LW + 2 + 2 * lane;
+	// (GEN: a third column, one further right, which only the last tile stores)
 	const int cidx = tid - 128;
-	const bool hcol = (cidx >= 0 && cidx < 2 * (TY + 2));
-	const int crr = cidx >> 1, cside = cidx & 1;
-	const long coff = (long)(y0 + crr - 1 + 1) * g.px + (cside ? c0 + TXW : c0 - 1);
+	const bool hcol = (cidx >= 0 && cidx < (GEN ? 3 : 2) * (TY + 2));
+	const int crr = GEN ? cidx % (TY + 2) : cidx >> 1, cside = GEN ? cidx / (TY + 2) : cidx & 1;
+	const int ccol = cside ? c0 + TXW + (cside - 1) : c0 - 1;
+	const long coff = (long)(y0 + crr - 1 + 1) * g.px + ccol;
 	const int cl = crr * LW + (cside ? 130 : 1);
+	// halo-column cells that are ghost / face cells of this tile's rows: updated here
+	const bool cstore = GEN && hcol && crr >= 1 && crr <= TY && (y0 + crr - 1) <= g.my + 1 &&
+	                    (cside ? (tx == a.ntx - 1 && ccol - 2 <= g.mx + 1) : tx == 0);
 
 	double2 pm[VD], pc[VD], pp[VD];
 	double2 dzm[VD], dzc[VD], dzp[VD];
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 #pragma unroll
 		for (int e = 0; e < VD; ++e) st2(buf + lidx[e], v[e]);
 		if (hrow) st2(buf + hl, UPD ? axpy2(hx, hy, cpsi) : hx);
-		if (hcol) buf[cl] = UPD ? axpy1(sx, sy, cpsi) : sx;
+		if (hcol && (!GEN || cside < 2)) buf[cl] = UPD ? axpy1(sx, sy, cpsi) : sx;
 	};
 	// store psi to its ping-pong partner at interior points of plane z
 	auto store_psi = [&](const double2 (&v)[VD], int z) {
@@ -453,6 +462,19 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				else if (uxx) a.Xout[pb + off[e]] = v[e].x;
 				else if (uxy) a.Xout[pb + off[e] + 1] = v[e].y;
 			}
+		}
+		if (GEN && cstore) a.Xout[pb + coff] = axpy1(sx, sy, cpsi);   // sx, sy still hold plane z
+	};
+	// the pointwise companions on the edge columns (GEN)
+	auto extras_col = [&](int z) {
+		if (!GEN || !cstore) return;
+		const long p = plane(z) + coff;
+		if (KIND == KF_A1) {
+			const double u0 = a.E[p], r0 = a.Ea[p];
+			a.phi[p] = axpy1(a.phi[p], u0, alpha_prev);
+			a.E[p] = axpy1(r0, u0, cpsi);
+		} else if (KIND == KF_B1L) {
+			a.E[p] = axpy1(a.E[p], a.Ea[p], cpsi);
 		}
 	};
 	// pointwise companions of plane z; returns the updated companion for dots
@@ -498,6 +520,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		if (KIND == KF_A1 || KIND == KF_B1L) {
 #pragma unroll
 			for (int e = 0; e < VD; ++e) { double2 d; extras(-1, e, d); }
+			extras_col(-1);
 		}
 	}
 	issue(z0);
@@ -521,6 +544,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		// plane 0 is a domain face or counted by the lower slab; with general
 		// boundaries the face plane mz is left to k_surf as well
 		const bool cnt = (z >= 1) && (!GEN || z <= g.mz - 1 || g.has_hi);
+		if (KIND == KF_A1 || KIND == KF_B1L) extras_col(z);
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			const long p = pb + off[e];
@@ -617,6 +641,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		if (KIND == KF_A1 || KIND == KF_B1L) {
 #pragma unroll
 			for (int e = 0; e < VD; ++e) { double2 d; extras(g.mz + 1, e, d); }
+			extras_col(g.mz + 1);
 		}
 	}
 
@@ -629,8 +654,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 // Boundary-plane terms of the dot products of a general-boundary fused kernel,
 // taken after the boundary treatment of its output: all points with i in {0,mx},
 // j in {0,my} or k on a z face of the domain, weighted 1/2 per boundary direction
-// (Krylov.C:180-233).  Its blocks append their partial sums to those of k_fused
-// and the last one finishes the reduction.  Item order: the z-face planes (x
+// (Krylov.C:180-233).  The threads that own the z-face points first apply the
+// z-face treatment to the output (the x and y faces are done by g_bc before).
+// Its blocks append their partial sums to those of k_fused and the last one
+// finishes the reduction.  Item order: the z-face planes (x
 // fastest), then the y-face rows of the other counted planes, then the x-face
 // columns of their inner rows.
 template <int KIND>
@@ -642,38 +669,62 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 	double acc[ND];
 #pragma unroll
 	for (int k = 0; k < ND; ++k) acc[k] = 0.;
-	const long nxy = (long)(g.mx + 1) * (g.my + 1);
-	const int nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
+	// item counts fit 32 bits for any grid the allocation limits allow (checked by the host)
+	const unsigned nx1 = g.mx + 1, ny1 = g.my + 1, nym = g.my - 1;
+	const unsigned nxy = nx1 * ny1;
+	const unsigned nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
 	const int k1 = 1, k2 = g.has_hi ? g.mz : g.mz - 1, nk = k2 - k1 + 1;
-	const long tz = nzf * nxy, ty = 2L * nk * (g.mx + 1), tx = 2L * nk * (g.my - 1);
-	const long total = tz + ty + tx;
-	for (long t = (long)blockIdx.x * NT + threadIdx.x; t < total; t += (long)gridDim.x * NT) {
+	const unsigned tz = nzf * nxy, ty = 2u * nk * nx1, tx = 2u * nk * nym;
+	const unsigned total = tz + ty + tx;
+	for (unsigned t = blockIdx.x * NT + threadIdx.x; t < total; t += gridDim.x * NT) {
 		int i, j, k;
 		bool bz = false;
 		if (t < tz) {
-			const int f = (int)(t / nxy);
-			const long rem = t - f * nxy;
-			j = (int)(rem / (g.mx + 1));
-			i = (int)(rem - (long)j * (g.mx + 1));
+			const unsigned f = t / nxy;
+			const unsigned rem = t - f * nxy;
+			j = (int)(rem / nx1);
+			i = (int)(rem - (unsigned)j * nx1);
 			k = (f == 0 && !g.has_lo) ? 0 : g.mz;
 			bz = true;
 		} else if (t < tz + ty) {
-			const long rem = t - tz;
-			const long r2 = rem / (g.mx + 1);
-			i = (int)(rem - r2 * (g.mx + 1));
+			const unsigned rem = t - tz;
+			const unsigned r2 = rem / nx1;
+			i = (int)(rem - r2 * nx1);
 			j = (r2 & 1) ? g.my : 0;
 			k = k1 + (int)(r2 >> 1);
 		} else {
-			const long rem = t - tz - ty;
-			const long r2 = rem / (g.my - 1);
-			j = 1 + (int)(rem - r2 * (g.my - 1));
+			const unsigned rem = t - tz - ty;
+			const unsigned r2 = rem / nym;
+			j = 1 + (int)(rem - r2 * nym);
 			i = (r2 & 1) ? g.mx : 0;
 			k = k1 + (int)(r2 >> 1);
 		}
 		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
 		const double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
 		const long p = kry_idx(g, i, j, k);
-		const double o = a.O[p];
+		double o;
+		if (bz) {
+			// the z-face treatment of the output (BoundaryHandler.C:528-566), done here by
+			// the one thread that owns the column; the x and y faces were treated before
+			const long s = g.ps;
+			double *c = a.O + p;
+			const int type = (k == 0) ? g.bc[4] : g.bc[5];
+			if (type == 0) {
+				o = 0.;
+				c[0] = 0.;
+				c[k == 0 ? -s : s] = 0.;
+			} else if (k == 0) {
+				c[-s] = 2. * c[0] - c[s];        // ghost first, from the old plane 0
+				o = 2. * c[s] - c[2 * s];
+				c[0] = o;
+			} else {
+				o = 2. * c[-s] - c[-2 * s];
+				c[0] = o;
+				c[s] = 2. * o - c[-s];
+			}
+		} else {
+			o = a.O[p];
+		}
 		if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
 			acc[0] += wgt * (o * a.RT[p]);
 		} else if (KIND == KF_B0L) {
@@ -1105,11 +1156,11 @@ hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n,
 	return hipGetLastError();
 }
 
-hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st)
+hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs)
 {
 	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.my + 3, 64), g.mz + 3), dim3(64), 0, st, d, g, 0);
 	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.mz + 3), dim3(64), 0, st, d, g, 1);
-	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
+	if (ndirs > 2) hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
 	return hipGetLastError();
 }
 

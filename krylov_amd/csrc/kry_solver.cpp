@@ -385,7 +385,7 @@ Tiling tiling(const kry_solver *h, const Slab &s)
 {
 	Tiling t;
 	if (h->gen) {
-		t.ntx = (s.g.mx + 4 + KRY_TXW - 1) / KRY_TXW;   // columns 0 .. mx+3 (i = -2 .. mx+1)
+		t.ntx = (s.g.mx + KRY_TXW - 1) / KRY_TXW;       // columns i = 0 .. mx-1; -1, mx, mx+1 by the halo lanes
 		t.nty = (s.g.my + 3 + 8 - 1) / 8;                // rows    j = -1 .. my+1
 		t.zlo = 0;
 		t.zhi = s.g.mz;
@@ -491,7 +491,7 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 			const int nsurf = surf_blocks(s.g);
 			a.red.nblk = a.nblk + nsurf;
 			CHK(launch_fused(h, s, kind, a, 1));
-			HIPCHK(kry_launch_bcs(a.O, s.g, s.st));
+			HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));   // the z faces follow in k_surf
 			a.blk_off = a.nblk;
 			HIPCHK(kry_launch_surf(kind, a, nsurf, s.st));
 			prof_end(h, s);
@@ -1079,7 +1079,9 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	// constant-coefficient operator re-applies the boundary treatment to its INPUT,
 	// Krylov.C:516, which cannot be folded into the producing update).
 	const bool can_fuse = h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
-	h->gen = can_fuse && !dirichlet && var;
+	bool extrapolating = true;     // every face of type 0 or 1
+	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
+	h->gen = can_fuse && !dirichlet && extrapolating && var;
 	h->fused = can_fuse && (dirichlet || h->gen);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
 	if (h->slabs.size() > 1 || h->comm.active()) {

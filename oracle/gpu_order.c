@@ -155,13 +155,13 @@ static double face_weight(const hbox *b, int i, int j, int k)
 	return (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
 }
 
-/* k_fused<GEN> (tiles start at column 0 and row j = -1, planes 0..mz, strict interior
+/* k_fused<GEN> (tiles start at i = 0 and row j = -1, planes 0..mz, strict interior
  * counted) followed by k_surf (boundary planes, weighted), one reduction over both */
 static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 {
 	const hbox b = hb(c);
 	const int ty = 8, zc = g_zc, VD = ty / NW;
-	const int ntx = (b.mx + 4 + 127) / 128, nty = (b.my + 3 + ty - 1) / ty;
+	const int ntx = (b.mx + 127) / 128, nty = (b.my + 3 + ty - 1) / ty;
 	const int zlo = 0, zhi = b.mz;
 	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
 	const long nf = (long)ntx * nty * nchunk;
@@ -182,7 +182,7 @@ static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 		double acc[NT];
 		for (int t = 0; t < NT; ++t) {
 			const int w = t >> 6, lane = t & 63;
-			const int i0 = 128 * tx + 2 * lane - 2;
+			const int i0 = 128 * tx + 2 * lane;
 			double s = 0.;
 			for (int z = z0; z < z1; ++z)
 				for (int e = 0; e < VD; ++e) {

@@ -35,7 +35,7 @@ def main():
     from test_gpu_multiproc import make_problem
     p = make_problem(kind)
     loc = SR.split_problem(P, p, world, rank)
-    flags = capi.KRY_FORCE_GENERIC if kind == "mixed" else 0
+    flags = capi.KRY_FORCE_GENERIC if kind == "mixed_generic" else 0
     with capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs=world,
                      slab_begin=rank, slab_count=1, devices=(0,)) as s:
         s.comm_init_callbacks(rank, world, allreduce, halo)

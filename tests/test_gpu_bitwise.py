@@ -134,6 +134,19 @@ def test_general_boundary_fused_path_with_offdiagonal_term(orc, L):
     assert_identical(want, got, min_passes=30)
 
 
+@pytest.mark.parametrize("L", [1, 2])
+def test_high_contrast_mixed_faces_workload(orc, L):
+    """The benchmark's anisotropic high-contrast problem (coefficient contrast 1e4,
+    x faces Dirichlet, y faces and the upper z face extrapolating) at 48^3."""
+    import bench
+    f = bench.slab_problem(48, 1, 0, "mixed")
+    p = P.Problem("mixed", f["mx"], f["delx"], f["bc"], True, False, (1., 1., 1.), f["phi"], f["rhs"], f["lam"],
+                  f["Dxx"], f["Dyy"], f["Dzz"], np.zeros_like(f["phi"]))
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=40)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=40)
+
+
 def test_summation_order_alone_moves_the_history(orc):
     """Reference order against device order, both on the CPU oracle: identical
     arithmetic, different summation order.  The histories agree at the start and

@@ -25,7 +25,7 @@ def make_problem(kind):
     elif kind == "var":
         p = P.smooth_var(32)
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
-    elif kind == "mixed":
+    elif kind in ("mixed", "mixed_generic"):
         p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
     else:
@@ -57,17 +57,17 @@ def run_ranks(world, kind, L, max_outer, eps, outdir):
 
 @gpu
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2)])
+@pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2), ("mixed", 1), ("mixed_generic", 2)])
 def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     from helpers import points, rel_l2
     from krylov_amd import capi
     p = make_problem(kind)
-    flags = capi.KRY_FORCE_GENERIC if kind == "mixed" else 0
+    flags = capi.KRY_FORCE_GENERIC if kind == "mixed_generic" else 0
     one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, flags=flags)
     parts = run_ranks(world, kind, L, 3, 1e-30, str(tmp_path))
     mzl = p.mx[2] // world
     for r, d in enumerate(parts):
-        assert int(d["iters"]) == 3 and bool(d["fused"]) == one["fused"]
+        assert int(d["iters"]) == 3 and int(d["fused"]) == one["path"]
         assert float(d["norm_rhs"]) == pytest.approx(one["norm_rhs"], rel=1e-13)
         assert np.max(np.abs(d["hist"] - one["history"])) <= 1e-10 * one["norm_rhs"]
         mine = d["phi"][1:mzl + 2, 1:-1, 1:-1]
