@@ -120,6 +120,12 @@ typedef int (*kry_halo_cb)(void *ctx, int peer_lo, const double *send_lo, double
 int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
                             void *ctx);
 
+/* The same callbacks with HOST pointers, for a transport that cannot read device
+ * memory (an MPI library without GPU support): the library stages the 8 sums and
+ * the two interface planes through pinned host buffers around each call. */
+int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
+                                 void *ctx);
+
 /* Replaces BICGStab::solve(bounds, phi, rhs, lambda, D_xx, D_yy, D_zz, debug)
  * (BICGStab3D/solveLin_BICGStab.C:200-215).  phi: initial guess in, solution
  * out.  Returns a status instead of calling exit(). */

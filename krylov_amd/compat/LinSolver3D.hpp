@@ -17,7 +17,11 @@ public:
 	virtual ~Linsolver3D() { my_type = -1; }
 
 	virtual void setup(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid, double epsilon_, NumArray<int> &solverPars,
-	                   bool spatial_diffusion, bool allow_offDiagDiffusion, int maxIter = 0) = 0;
+	                   bool spatial_diffusion, bool allow_offDiagDiffusion,
+#ifdef parallel
+	                   mpi_manager_3D &MyMPI,
+#endif
+	                   int maxIter = 0) = 0;
 
 	// constant diagonal diffusion tensor
 	virtual void solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
@@ -41,6 +45,9 @@ protected:
 	                       NumMatrix<double, 3> &lambda, NumMatrix<double, 3> &Dxx, NumMatrix<double, 3> &Dyy,
 	                       NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug = 0) = 0;
 	virtual void set_Grid(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid) = 0;
+#ifdef parallel
+	MPI_Comm comm3d;
+#endif
 	int dim, rank;
 	int debug;
 };

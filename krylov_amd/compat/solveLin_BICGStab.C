@@ -18,6 +18,10 @@ BICGStab::BICGStab()
 	my_type = 20;
 	for (int d = 0; d < 3; ++d) { delx[d] = 1.; DiffDiag[d] = 1.; mx[d] = 0; }
 	for (int f = 0; f < 6; ++f) handle_bc[f] = -99;
+#ifdef parallel
+	comm3d = MPI_COMM_NULL;
+	nslabs_mpi = 1; slab_mpi = 0; nb_lo = nb_hi = MPI_PROC_NULL;
+#endif
 	devices.push_back(0);
 	// KRY_DEVICES=0,1,2,... : one z slab per listed device
 	if (const char *e = getenv("KRY_DEVICES")) {
@@ -33,8 +37,14 @@ BICGStab::BICGStab()
 	}
 }
 
+#ifdef parallel
+BICGStab::BICGStab(grid_manager &TheGrid, double tol, int LValue_, mpi_manager_3D &MyMPI, bool, bool) : BICGStab()
+{
+	use_MPI(MyMPI);
+#else
 BICGStab::BICGStab(grid_manager &TheGrid, double tol, int LValue_, bool, bool) : BICGStab()
 {
+#endif
 	// BICGStab3D/solveLin_BICGStab.C:104-131
 	LValue = LValue_;
 	for (int d = 0; d < 3; ++d) {
@@ -52,12 +62,56 @@ void BICGStab::release()
 	handle = NULL;
 }
 
+#ifdef parallel
+// The device solver splits the domain along z only (BICGStab3D/solveLin_BICGStab.C:
+// 142-147 takes comm3d and the rank from the manager).
+void BICGStab::use_MPI(mpi_manager_3D &MyMPI)
+{
+	comm3d = MyMPI.comm3d;
+	rank = MyMPI.get_rank();
+	if (MyMPI.get_nproc(0) != 1 || MyMPI.get_nproc(1) != 1) {
+		if (rank == 0)
+			cerr << " BICGStab: the device solver decomposes along z only; use nproc = {1, 1, P} instead of {"
+			     << MyMPI.get_nproc(0) << ", " << MyMPI.get_nproc(1) << ", " << MyMPI.get_nproc(2) << "}" << endl;
+		MyMPI.Finalise();
+	}
+	nslabs_mpi = MyMPI.get_nproc(2);
+	slab_mpi = MyMPI.get_coord(2);
+	nb_lo = MyMPI.get_bottom();
+	nb_hi = MyMPI.get_top();
+}
+
+int BICGStab::mpi_allreduce(void *ctx, double *buf, int n)
+{
+	// Krylov.C:237-242
+	BICGStab *self = static_cast<BICGStab *>(ctx);
+	return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, MPI_SUM, self->comm3d) == MPI_SUCCESS ? 0 : 1;
+}
+
+int BICGStab::mpi_halo(void *ctx, int, const double *send_lo, double *recv_lo, int, const double *send_hi,
+                       double *recv_hi, unsigned long count)
+{
+	// BoundaryHandler.C:1633-1677 for direction 2
+	BICGStab *self = static_cast<BICGStab *>(ctx);
+	int e1 = MPI_Sendrecv(send_lo, (int)count, MPI_DOUBLE, self->nb_lo, 81, recv_hi, (int)count, MPI_DOUBLE, self->nb_hi,
+	                      81, self->comm3d, MPI_STATUS_IGNORE);
+	int e2 = MPI_Sendrecv(send_hi, (int)count, MPI_DOUBLE, self->nb_hi, 82, recv_lo, (int)count, MPI_DOUBLE, self->nb_lo,
+	                      82, self->comm3d, MPI_STATUS_IGNORE);
+	return (e1 == MPI_SUCCESS && e2 == MPI_SUCCESS) ? 0 : 1;
+}
+
+void BICGStab::setup(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid, double epsilon_, NumArray<int> &solverPars, bool,
+                     bool, mpi_manager_3D &MyMPI, int maxIter)
+{
+	use_MPI(MyMPI);
+#else
 void BICGStab::setup(grid_1D &xGrid, grid_1D &yGrid, grid_1D &zGrid, double epsilon_, NumArray<int> &solverPars, bool,
                      bool, int maxIter)
 {
 	// BICGStab3D/solveLin_BICGStab.C:134-157.  maxIter is accepted and ignored
 	// there; here a positive value caps the outer passes.
 	rank = 0;
+#endif
 	eps = epsilon_;
 	LValue = solverPars(0);
 	dim = 3;
@@ -103,11 +157,19 @@ void BICGStab::ensure_handle(BoundaryHandler3D &bounds, const NumMatrix<double, 
 	d.L = LValue;
 	d.eps = eps;
 	d.max_outer = max_outer;
+#ifdef parallel
+	// one slab per process; process r uses the (r mod listed)-th listed device
+	d.nslabs = nslabs_mpi;
+	d.slab_begin = slab_mpi;
+	d.slab_count = 1;
+	d.devices[0] = devices[slab_mpi % devices.size()];
+#else
 	int ns = (int)devices.size();
 	while (ns > 1 && (mx[2] % ns != 0 || mx[2] / ns < 4)) --ns;
 	d.nslabs = d.slab_count = ns;
 	d.slab_begin = 0;
 	for (int i = 0; i < ns; ++i) d.devices[i] = devices[i];
+#endif
 	int st = 0;
 	handle = kry_create(&d, &st);
 	if (!handle) {
@@ -115,6 +177,13 @@ void BICGStab::ensure_handle(BoundaryHandler3D &bounds, const NumMatrix<double, 
 		     << ")" << endl;
 		exit(2);
 	}
+#ifdef parallel
+	if (nslabs_mpi > 1 &&
+	    kry_comm_init_host_callbacks(handle, slab_mpi, nslabs_mpi, &BICGStab::mpi_allreduce, &BICGStab::mpi_halo, this) != 0) {
+		cerr << " BICGStab: cannot attach the MPI transport (" << kry_last_error() << ")" << endl;
+		exit(2);
+	}
+#endif
 }
 
 void BICGStab::finish(int st)

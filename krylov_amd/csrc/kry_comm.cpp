@@ -106,16 +106,50 @@ int KryComm::init_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, v
 	return 0;
 }
 
+int KryComm::init_host_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx)
+{
+	int st = init_callbacks(rank, nranks, ar, hl, ctx);
+	if (st == 0) cb_host_ = true;
+	return st;
+}
+
+int KryComm::ensure_stage(size_t count)
+{
+	if (count <= stage_cap_) return 0;
+	if (stage_) hipHostFree(stage_);
+	stage_ = nullptr;
+	stage_cap_ = 0;
+	if (hipHostMalloc((void **)&stage_, 4 * count * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+		g_cerr = "cannot allocate pinned staging buffers";
+		return -2;
+	}
+	stage_cap_ = count;
+	return 0;
+}
+
 void KryComm::destroy()
 {
 	cb_allreduce_ = nullptr;
 	cb_halo_ = nullptr;
+	cb_host_ = false;
+	if (stage_) hipHostFree(stage_);
+	stage_ = nullptr;
+	stage_cap_ = 0;
 	if (comm_ && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(comm_));
 	comm_ = nullptr;
 }
 
 int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
 {
+	if (cb_allreduce_ && cb_host_) {
+		if (ensure_stage(64) != 0) return -2;
+		if (hipMemcpyAsync(stage_, buf, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess) { g_cerr = "staging copy failed"; return -2; }
+		if (cb_allreduce_(cb_ctx_, stage_, n) != 0) { g_cerr = "allreduce callback failed"; return -3; }
+		if (hipMemcpyAsync(buf, stage_, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess) { g_cerr = "staging copy failed"; return -2; }
+		return 0;
+	}
 	if (cb_allreduce_) {
 		if (hipStreamSynchronize(st) != hipSuccess) { g_cerr = "stream synchronize failed"; return -2; }
 		if (cb_allreduce_(cb_ctx_, buf, n) != 0) { g_cerr = "allreduce callback failed"; return -3; }
@@ -129,6 +163,25 @@ int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_
                   double *recv_hi, size_t count, hipStream_t st)
 {
 	if (peer_lo < 0 && peer_hi < 0) return 0;
+	if (cb_halo_ && cb_host_) {
+		if (ensure_stage(count) != 0) return -2;
+		double *slo = stage_, *shi = stage_ + count, *rlo = stage_ + 2 * count, *rhi = stage_ + 3 * count;
+		const size_t bytes = count * sizeof(double);
+		bool ok = true;
+		if (peer_lo >= 0) ok = ok && hipMemcpyAsync(slo, send_lo, bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+		if (peer_hi >= 0) ok = ok && hipMemcpyAsync(shi, send_hi, bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+		ok = ok && hipStreamSynchronize(st) == hipSuccess;
+		if (!ok) { g_cerr = "staging copy failed"; return -2; }
+		if (cb_halo_(cb_ctx_, peer_lo, slo, rlo, peer_hi, shi, rhi, (unsigned long)count) != 0) {
+			g_cerr = "halo callback failed";
+			return -3;
+		}
+		if (peer_lo >= 0) ok = ok && hipMemcpyAsync(recv_lo, rlo, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+		if (peer_hi >= 0) ok = ok && hipMemcpyAsync(recv_hi, rhi, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+		ok = ok && hipStreamSynchronize(st) == hipSuccess;
+		if (!ok) { g_cerr = "staging copy failed"; return -2; }
+		return 0;
+	}
 	if (cb_halo_) {
 		if (hipStreamSynchronize(st) != hipSuccess) { g_cerr = "stream synchronize failed"; return -2; }
 		if (cb_halo_(cb_ctx_, peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (unsigned long)count) != 0) {

@@ -19,6 +19,8 @@ public:
 	typedef int (*allreduce_fn)(void *, double *, int);
 	typedef int (*halo_fn)(void *, int, const double *, double *, int, const double *, double *, unsigned long);
 	int init_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx);
+	// the same with HOST pointers: the data is staged through pinned buffers here
+	int init_host_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx);
 	void destroy();
 	bool active() const { return comm_ != nullptr || cb_allreduce_ != nullptr; }
 	int rank() const { return rank_; }
@@ -36,5 +38,9 @@ private:
 	allreduce_fn cb_allreduce_ = nullptr;
 	halo_fn cb_halo_ = nullptr;
 	void *cb_ctx_ = nullptr;
+	bool cb_host_ = false;          // callbacks take host pointers
+	double *stage_ = nullptr;       // pinned: [send_lo | send_hi | recv_lo | recv_hi], each stage_cap_ doubles
+	size_t stage_cap_ = 0;
+	int ensure_stage(size_t count);
 	int rank_ = 0, nranks_ = 1;
 };

@@ -1315,6 +1315,21 @@ int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb
 	return st;
 }
 
+int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
+                                 void *ctx)
+{
+	if (!h) { set_err("null argument"); return KRY_ERR_ARG; }
+	if (h->d.slab_count != 1 || h->d.nslabs != nranks || h->d.slab_begin != rank) {
+		set_err("kry_comm_init_host_callbacks: rank r must own exactly slab r (nslabs=%d begin=%d count=%d, rank=%d/%d)",
+		        h->d.nslabs, h->d.slab_begin, h->d.slab_count, rank, nranks);
+		return KRY_ERR_ARG;
+	}
+	hipSetDevice(h->slabs[0].device);
+	int st = h->comm.init_host_callbacks(rank, nranks, allreduce, halo, ctx);
+	if (st < 0) set_err("%s", KryComm::last_error());
+	return st;
+}
+
 int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda, double Dxx,
                    double Dyy, double Dzz)
 {

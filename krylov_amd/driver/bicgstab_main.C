@@ -7,6 +7,11 @@
 // Linsolver3D interface and report the l2 error against the analytic solution.
 //
 //   bicgstab [-n MX] [-t 1..5] [-r] [-l L] [-e TOL] [-i MAXITER] [--stats] [-q]
+//
+// Built with -D parallel (and an MPI installation) it is the reference's parallel
+// driver: `mpiexec -n P bicgstab_mpi ...` splits the domain into P z slabs
+// (nproc = {1, 1, P}; the reference hard-codes {2, 2, 2}, BICGStab3D/main.C:145-150),
+// one process and one GPU each (KRY_DEVICES lists the devices, default all on 0).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -92,21 +97,47 @@ bool parse(int argc, char **argv, Options &o)
 
 int main(int argc, char *argv[])
 {
+#ifdef parallel
+	int ntasks = 1, rank = 0;                 // BICGStab3D/main.C:58-63
+	MPI_Init(&argc, &argv);
+	MPI_Comm_size(MPI_COMM_WORLD, &ntasks);
+	MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+#else
+	const int rank = 0;
+#endif
 	Options opt;
 	if (!parse(argc, argv, opt)) return EXIT_FAILURE;
-	if (!opt.stats) cout << "Problem size: " << opt.mx << ", running test " << opt.test << endl;
+	if (rank != 0) opt.quiet = true;
+	const bool talk = !opt.stats && rank == 0;
+	if (talk) cout << "Problem size: " << opt.mx << ", running test " << opt.test << endl;
 
 	const int N = opt.mx + 1;
 	grid_manager MyGrid(0., 0., 0., 1., 1., 1., N, N, N, 1);
 	grid_1D grid_x(0, 1, N, 2, 0, true), grid_y(0, 1, N, 2, 0, true), grid_z(0, 1, N, 2, 0, true);
 	for (int b = 0; b < 6; ++b) MyGrid.set_bcType(b, 0);
 
+#ifdef parallel
+	// BICGStab3D/main.C:145-186, with the split along z
+	NumArray<int> nproc(3), mx_global(3);
+	nproc[0] = 1; nproc[1] = 1; nproc[2] = ntasks;
+	mx_global[0] = mx_global[1] = mx_global[2] = opt.mx;
+	mpi_manager_3D MyMPI(nproc, mx_global);
+	grid_manager LocalGrid = MyMPI.make_LocalGrid(MyGrid);
+	grid_1D grid_x_local = MyMPI.make_LocalGrid1D(grid_x, 0);
+	grid_1D grid_y_local = MyMPI.make_LocalGrid1D(grid_y, 1);
+	grid_1D grid_z_local = MyMPI.make_LocalGrid1D(grid_z, 2);
+	BoundaryHandler3D MyBounds(MyMPI);
+	grid_manager &PosGrid = LocalGrid;
+	const int m = LocalGrid.get_mx(0), my_ = LocalGrid.get_mx(1), mz_ = LocalGrid.get_mx(2);
+#else
 	BoundaryHandler3D MyBounds;
+	grid_manager &PosGrid = MyGrid;
+	const int m = opt.mx, my_ = opt.mx, mz_ = opt.mx;
+#endif
 	MyBounds.set_bcType(0);                   // all faces Dirichlet (BICGStab3D/main.C:187)
 
-	const int m = opt.mx;
 	NumMatrix<double, 3> phi, phi_ana, rhs, lambda, D[4];
-	const Index lo = Index::set(-1, -1, -1), hi = Index::set(m + 1, m + 1, m + 1);
+	const Index lo = Index::set(-1, -1, -1), hi = Index::set(m + 1, my_ + 1, mz_ + 1);
 	phi.resize(lo, hi); phi_ana.resize(lo, hi); rhs.resize(lo, hi); lambda.resize(lo, hi);
 	for (int k = 0; k < 4; ++k) D[k].resize(lo, hi);
 	D[0].set_constVal(1.); D[1].set_constVal(1.); D[2].set_constVal(1.); D[3].clear();
@@ -121,10 +152,12 @@ int main(int argc, char *argv[])
 	}
 	const double DPar = 1., DPerp = 0.1;
 
-	for (int iz = 0; iz <= m; ++iz)
-		for (int iy = 0; iy <= m; ++iy)
+	for (int iz = 0; iz <= mz_; ++iz)
+		for (int iy = 0; iy <= my_; ++iy)
 			for (int ix = 0; ix <= m; ++ix) {
-				const double x = MyGrid.get_Pos(0, ix), y = MyGrid.get_Pos(1, iy), z = MyGrid.get_Pos(2, iz);
+				const double x = PosGrid.get_Pos(0, ix), y = PosGrid.get_Pos(1, iy), z = PosGrid.get_Pos(2, iz);
+				// faces of the global domain (the unit-tensor test zeroes its solution there)
+				const bool top_face = (x >= 1. - 1e-12) || (y >= 1. - 1e-12) || (z >= 1. - 1e-12);
 				const double sx = sin(pi * x), sy = sin(pi * y), sz = sin(pi * z);
 				const double cx = cos(pi * x), cy = cos(pi * y), cz = cos(pi * z);
 				const double ana = sx * sy * sz;
@@ -167,56 +200,72 @@ int main(int argc, char *argv[])
 					break;
 				}
 				default:  // test 5: unit tensor fields through the field interface (main.C:313-336)
-					if (ix == m || iy == m || iz == m) phi_ana(ix, iy, iz) = 0.;
+					if (top_face) phi_ana(ix, iy, iz) = 0.;
 					D[0](ix, iy, iz) = dfac[0]; D[1](ix, iy, iz) = dfac[1]; D[2](ix, iy, iz) = dfac[2]; D[3](ix, iy, iz) = 0.;
 					rhs(ix, iy, iz) = -(sqr(pi) * (1. + 1. + 1.) + lam) * phi_ana(ix, iy, iz);
 					break;
 				}
 			}
 
-	if (!opt.stats) cout << " bauen " << endl;
+	if (talk) cout << " bauen " << endl;
 	Linsolver3D *lin_solver = new BICGStab();
 	NumArray<int> pars(1);
 	pars(0) = opt.L;
+#ifdef parallel
+	lin_solver->setup(grid_x_local, grid_y_local, grid_z_local, opt.tol, pars, false, false, MyMPI, opt.max_iter);
+#else
 	lin_solver->setup(grid_x, grid_y, grid_z, opt.tol, pars, false, false, opt.max_iter);
+#endif
 
-	if (!opt.stats) cout << " lösen " << endl;
+	if (talk) cout << " lösen " << endl;
 	const int dbg = (opt.quiet || opt.stats) ? 0 : 8;
 	const auto t0 = chrono::steady_clock::now();
 	if (opt.test == 1) lin_solver->solve(MyBounds, phi, rhs, lambda, Diff[0], Diff[1], Diff[2], dbg);
 	else if (opt.test == 2 || opt.test == 5) lin_solver->solve(MyBounds, phi, rhs, lambda, D[0], D[1], D[2], D[3], dbg);
 	else lin_solver->solve(MyBounds, phi, rhs, lambda, D[0], D[1], D[2], D[3], dbg, true);
 	const double runtime = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
-	if (!opt.stats) cout << "Solver fertig in " << (long long)runtime << " ms" << endl;
+	if (talk) cout << "Solver fertig in " << (long long)runtime << " ms" << endl;
 
 	// l2 and max error against the analytic solution (main.C:503-567)
 	double error = 0., num = 0., emax = 0.;
-	for (int iz = 0; iz <= m; ++iz)
-		for (int iy = 0; iy <= m; ++iy)
+	for (int iz = 0; iz <= mz_; ++iz)
+		for (int iy = 0; iy <= my_; ++iy)
 			for (int ix = 0; ix <= m; ++ix) {
 				const double d = phi_ana(ix, iy, iz) - phi(ix, iy, iz);
 				error += sqr(d);
 				num += 1.;
 				emax = max(emax, fabs(d));
 			}
+#ifdef parallel
+	// main.C:550-560 (interface planes are counted by both owners there as well)
+	double g[2] = {error, num}, gm = emax;
+	MPI_Allreduce(MPI_IN_PLACE, g, 2, MPI_DOUBLE, MPI_SUM, MyMPI.comm3d);
+	MPI_Allreduce(MPI_IN_PLACE, &gm, 1, MPI_DOUBLE, MPI_MAX, MyMPI.comm3d);
+	error = g[0]; num = g[1]; emax = gm;
+#endif
 	const double l2err = sqrt(error / num);
 
 	BICGStab *bs = static_cast<BICGStab *>(lin_solver);
-	if (opt.stats) {
+	if (rank != 0) {
+		// only the first process reports
+	} else if (opt.stats) {
 		// columns of the reference's --stats row (BiCGStab3D_CL/main.cpp:576,600-602)
 		const int it = bs->iterations();
 		const double calc = bs->solveRuntime();
 		const double avg = it > 0 ? calc / it : 0.;
 		cout << "# Test, Size, Iterations, Total runtime, Calculation time, Min step time, Max step time, "
 		        "Average (arithmetic), Average (geometric), Tolerance, L2 error, Max error" << endl;
-		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, m, it, runtime, calc, avg, avg,
-		       avg, avg, opt.tol, l2err, emax);
+		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, opt.mx, it, runtime, calc, avg,
+		       avg, avg, avg, opt.tol, l2err, emax);
 	} else {
-		cout << " l2 error for " << m << " is " << l2err << endl;
+		cout << " l2 error for " << opt.mx << " is " << l2err << endl;
 		cout << "Runtime (solver) : " << (long long)runtime << " ms" << endl;
 		cout << "Iterations       : " << bs->iterations() << " (" << bs->solveRuntime() << " ms on the device, "
 		     << (bs->usedFusedKernels() ? "fused" : "generic") << " kernels)" << endl;
 	}
 	delete lin_solver;
+#ifdef parallel
+	MPI_Finalize();                           // main.C:577-579
+#endif
 	return EXIT_SUCCESS;
 }

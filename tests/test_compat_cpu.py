@@ -57,3 +57,22 @@ def test_grid_numbers(shim, N):
     if (N - 1) & (N - 2) == 0:
         assert d2.value == d1.value
     assert np.array_equal(pos, 0.0 + d1.value * np.arange(-1, N + 1))
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+MPI_SELFTEST = os.path.join(ROOT, "krylov_amd", "driver", "compat_mpi_selftest")
+
+
+@pytest.mark.parametrize("nproc", [(1, 1, 2), (1, 1, 4), (2, 2, 2)])
+def test_parallel_flavour_topology_and_plane_exchange(nproc):
+    """The `-D parallel` classes (mpi_manager_3D, BoundaryHandler3D with a process
+    topology) under a real MPI: rank layout, local grids, outer-face flags and the
+    ghost-plane exchange of do_BCs.  Host only."""
+    import subprocess
+    if not (os.path.exists(MPIEXEC) and os.path.exists(MPI_SELFTEST)):
+        pytest.skip("no MPI installation / parallel flavour not built")
+    n = nproc[0] * nproc[1] * nproc[2]
+    out = subprocess.run([MPIEXEC, "-n", str(n), MPI_SELFTEST] + [str(v) for v in nproc], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "selftest ok" in out.stdout

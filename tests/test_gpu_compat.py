@@ -94,3 +94,32 @@ def test_driver_stats_row():
     rows = [l for l in out.stdout.splitlines() if l and not l.startswith("#")]
     cols = rows[-1].split(",")
     assert len(cols) == 12 and int(cols[0]) == 2 and int(cols[1]) == 24 and int(cols[2]) > 0
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+DRIVER_MPI = os.path.join(ROOT, "krylov_amd", "driver", "bicgstab_mpi")
+
+
+def _l2(txt):
+    return float(re.search(r"l2 error for \d+ is ([-+0-9.eE]+)", txt).group(1))
+
+
+@pytest.mark.parametrize("test,nproc", [(1, 2), (2, 2), (3, 4), (5, 2)])
+def test_parallel_driver_under_mpi(test, nproc):
+    """The reference's `-D parallel` driver flow (mpi_manager_3D, local grids,
+    BoundaryHandler3D(MyMPI), setup(..., MyMPI)) with one process per z slab and MPI
+    as the transport behind the library's host-callback hooks; all processes share
+    GPU 0 here.  Same l2 error as the serial driver."""
+    if not (os.path.exists(MPIEXEC) and os.path.exists(DRIVER_MPI)):
+        pytest.skip("no MPI installation / parallel flavour not built")
+    serial = subprocess.run([DRIVER, "-n", "32", "-t", str(test), "-q"], capture_output=True, text=True, timeout=120)
+    assert serial.returncode == 0, serial.stderr
+    par = subprocess.run([MPIEXEC, "-n", str(nproc), DRIVER_MPI, "-n", "32", "-t", str(test), "-q"],
+                         capture_output=True, text=True, timeout=240)
+    assert par.returncode == 0, par.stdout + par.stderr
+    assert "Number of tasks: %d" % nproc in par.stdout
+    a, b = _l2(serial.stdout), _l2(par.stdout)
+    assert b == pytest.approx(a, rel=2e-2)        # both converged to 1e-6; the error is the discretisation's
+    ia = int(re.search(r"Iterations\s*:\s*(\d+)", serial.stdout).group(1))
+    ib = int(re.search(r"Iterations\s*:\s*(\d+)", par.stdout).group(1))
+    assert abs(ia - ib) <= max(6, ia // 3)
