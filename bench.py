@@ -39,15 +39,15 @@ def kernel_words(L, var, offd):
     array touched once per kernel, stencil neighbours served on chip)."""
     d = (4 if offd else 3) if var else 0
     if L == 1:
-        return {0: 6 + d,          # r0,u0,lam,rt -> u0,u1
+        return {0: 7 + d,          # r0,u0,u1(old),lam,rt -> u0,u1
                 3: 5 + d,          # r0,u1,lam -> r0,r1
-                7: 9}              # phi,u0,r0,r1,u1,rt -> phi,r0,u0
-    return {0: 6 + d,              # r0,u0,lam,rt -> u0,u1
+                7: 7}              # phi,u0,r0,r1,rt -> phi,r0   (the u0 update rides in the next pass's first kernel)
+    return {0: 8 + d,              # r0,u0,u1(old),u2(old),lam,rt -> u0,u1
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
             1: 11 + d,             # r1,u1,lam,rt,phi,u0,r0 -> u1,u2,phi,u0
             4: 8 + d,              # r1,u2,lam,r0,u1 -> r1,r2,r0
             6: 3,                  # r2,r1,r0 -> dots only (r2' is recomputed by the last kernel)
-            7: 11}                 # phi,r0..r2,u0..u2,rt -> phi,r0,u0
+            7: 8}                  # phi,r0..r2,u0,rt -> phi,r0
 
 
 def measured_traffic(kernel_name, n, L, workload, world):

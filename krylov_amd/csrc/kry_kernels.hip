@@ -350,6 +350,12 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 
 	const double cpsi = UPD ? (IS_A ? -S->beta : -S->alpha) : 0.;
 	const double alpha_prev = (KIND == KF_A1) ? S->alpha : 0.;
+	// KF_A0 first applies the u0 update that closed the previous pass
+	// (solveLin_BICGStab.C:452, 458-459): u0 -= gamma_L*u_L [; u0 -= gamma_1*u_1],
+	// so the end-of-pass kernel neither reads u_1..u_L nor writes u0.
+	constexpr bool DEFER = (KIND == KF_A0);
+	const int nz = DEFER ? a.nz : 0;
+	const double dz1 = DEFER ? -S->gamma[S->L] : 0., dz2 = DEFER ? -S->gamma[1] : 0.;
 
 	// XCD-aware block -> tile map: blocks that share blockIdx%8 get neighbouring tiles
 	int bid;
@@ -414,8 +420,9 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	double2 pm[VD], pc[VD], pp[VD];
 	double2 dzm[VD], dzc[VD], dzp[VD];
 	double2 nx[VD], ny[VD];
-	double2 hx = {0., 0.}, hy = {0., 0.};
-	double sx = 0., sy = 0.;
+	double2 nz1[DEFER ? VD : 1], nz2[DEFER ? VD : 1];
+	double2 hx = {0., 0.}, hy = {0., 0.}, hz1 = {0., 0.}, hz2 = {0., 0.};
+	double sx = 0., sy = 0., sz1 = 0., sz2 = 0.;
 	double acc[ND];
 #pragma unroll
 	for (int k = 0; k < ND; ++k) acc[k] = 0.;
@@ -429,27 +436,46 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		for (int e = 0; e < VD; ++e) {
 			nx[e] = ld2(a.X + pb + off[e]);
 			if (UPD) ny[e] = ld2(a.Y + pb + off[e]);
+			if (DEFER && nz >= 1) nz1[DEFER ? e : 0] = ld2(a.Z1 + pb + off[e]);
+			if (DEFER && nz >= 2) nz2[DEFER ? e : 0] = ld2(a.Z2 + pb + off[e]);
 		}
 		if (hrow) {
 			hx = ld2(a.X + pb + hoff);
 			if (UPD) hy = ld2(a.Y + pb + hoff);
+			if (DEFER && nz >= 1) hz1 = ld2(a.Z1 + pb + hoff);
+			if (DEFER && nz >= 2) hz2 = ld2(a.Z2 + pb + hoff);
 		}
 		if (hcol) {
 			sx = a.X[pb + coff];
 			if (UPD) sy = a.Y[pb + coff];
+			if (DEFER && nz >= 1) sz1 = a.Z1[pb + coff];
+			if (DEFER && nz >= 2) sz2 = a.Z2[pb + coff];
 		}
+	};
+	// psi = X + c*Y, with Y first brought up to date where its last update was deferred
+	auto psi2 = [&](double2 x, double2 y, double2 z1, double2 z2) -> double2 {
+		if (!UPD) return x;
+		if (DEFER && nz >= 1) y = axpy2(y, z1, dz1);
+		if (DEFER && nz >= 2) y = axpy2(y, z2, dz2);
+		return axpy2(x, y, cpsi);
+	};
+	auto psi1 = [&](double x, double y, double z1, double z2) -> double {
+		if (!UPD) return x;
+		if (DEFER && nz >= 1) y = axpy1(y, z1, dz1);
+		if (DEFER && nz >= 2) y = axpy1(y, z2, dz2);
+		return axpy1(x, y, cpsi);
 	};
 	// psi of the issued plane at the own points
 	auto own_psi = [&](double2 (&dst)[VD]) {
 #pragma unroll
-		for (int e = 0; e < VD; ++e) dst[e] = UPD ? axpy2(nx[e], ny[e], cpsi) : nx[e];
+		for (int e = 0; e < VD; ++e) dst[e] = psi2(nx[e], ny[e], nz1[DEFER ? e : 0], nz2[DEFER ? e : 0]);
 	};
 	// write psi (own + halo) of the issued plane into an LDS buffer
 	auto to_lds = [&](const double2 (&v)[VD], double *buf) {
 #pragma unroll
 		for (int e = 0; e < VD; ++e) st2(buf + lidx[e], v[e]);
-		if (hrow) st2(buf + hl, UPD ? axpy2(hx, hy, cpsi) : hx);
-		if (hcol && (!GEN || cside < 2)) buf[cl] = UPD ? axpy1(sx, sy, cpsi) : sx;
+		if (hrow) st2(buf + hl, psi2(hx, hy, hz1, hz2));
+		if (hcol && (!GEN || cside < 2)) buf[cl] = psi1(sx, sy, sz1, sz2);
 	};
 	// store psi to its ping-pong partner at interior points of plane z
 	auto store_psi = [&](const double2 (&v)[VD], int z) {
@@ -463,7 +489,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				else if (uxy) a.Xout[pb + off[e] + 1] = v[e].y;
 			}
 		}
-		if (GEN && cstore) a.Xout[pb + coff] = axpy1(sx, sy, cpsi);   // sx, sy still hold plane z
+		if (GEN && cstore) a.Xout[pb + coff] = psi1(sx, sy, sz1, sz2);   // sx, sy, ... still hold plane z
 	};
 	// the pointwise companions on the edge columns (GEN)
 	auto extras_col = [&](int z) {
@@ -819,10 +845,11 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 
 // End of an outer pass (solveLin_BICGStab.C:403, 450-464):
 //   phi += alpha*u0 (deferred from the last BiCG step); phi += gamma1*r0;
-//   r0 -= gammap_L*r_L; u0 -= gamma_L*u_L; then for jj = 1..L-1:
-//   u0 -= gamma_jj*u_jj; phi += gammapp_jj*r_jj; r0 -= gammap_jj*r_jj;
+//   r0 -= gammap_L*r_L; then for jj = 1..L-1: phi += gammapp_jj*r_jj; r0 -= gammap_jj*r_jj;
 //   dots |r0|^2 and (r0, r~).
-// v[0..L] = r0..rL, v[L+1..2L+1] = u0..uL, v[2L+2] = r~, w[0] = phi, w[1] = r0, w[2] = u0.
+// The u0 updates of these lines (u0 -= gamma_L*u_L; u0 -= gamma_jj*u_jj) are left to
+// the next pass's first stencil kernel, which reads u0 anyway.
+// v[0..L] = r0..rL, v[L+1] = u0, v[L+2] = r~, w[0] = phi, w[1] = r0.
 template <int L, bool GEN>
 __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 {
@@ -846,15 +873,16 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
-		double2 r[UN][L + 1], u[UN][L + 1], ph[UN], rt[UN];
+		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN];
 		// all loads first (reads past the end of a plane stay inside the allocation)
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long p = pb + q0 + 2L * i * NT;
 #pragma unroll
-			for (int j = 0; j <= L; ++j) { r[i][j] = ld2s(a.v[j] + p); u[i][j] = ld2s(a.v[L + 1 + j] + p); }
+			for (int j = 0; j <= L; ++j) r[i][j] = ld2s(a.v[j] + p);
+			u0[i] = ld2s(a.v[L + 1] + p);
 			ph[i] = ld2s(a.w[0] + p);
-			rt[i] = ld2s(a.v[2 * L + 2] + p);
+			rt[i] = ld2s(a.v[L + 2] + p);
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
@@ -862,19 +890,16 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			if (q < a.g.ps) {
 				const long p = pb + q;
 				if (L == 2) r[i][2] = axpy2(r[i][2], r[i][1], ntau12);   // the Gram-Schmidt step of k_mgs2
-				double2 phv = axpy2(ph[i], u[i][0], alpha);
+				double2 phv = axpy2(ph[i], u0[i], alpha);
 				phv = axpy2(phv, r[i][0], g1[1]);
 				double2 r0 = axpy2(r[i][0], r[i][L], -gp[L]);
-				double2 u0 = axpy2(u[i][0], u[i][L], -g1[L]);
 #pragma unroll
 				for (int j = 1; j < L; ++j) {
-					u0 = axpy2(u0, u[i][j], -g1[j]);
 					phv = axpy2(phv, r[i][j], gpp[j]);
 					r0 = axpy2(r0, r[i][j], -gp[j]);
 				}
 				st2s(a.w[0] + p, phv);
 				st2s(a.w[1] + p, r0);
-				st2s(a.w[2] + p, u0);
 				if (GEN) {
 					if (cnt) {
 						// |r0|^2 with the norm's weights (corners 1/4, Krylov.C:136-143),

@@ -547,11 +547,16 @@ int fused_pass(kry_solver *h, int it)
 		return 0;
 	};
 
-	// --- jj = 0, A: u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
+	// u1 lives in ub[1][.]: l = 1 alternates the two buffers with the pass (the A kernel
+	// reads the old u1 from one and writes the new one to the other); l = 2 writes the
+	// operator output to [1] and the updated u1 (A kernel of jj = 1) back to [0]
+	// --- jj = 0, A: u0 -= gamma_L*u_L [- gamma_1*u_1] (previous pass) ; u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
 	CHK(stencil_step(h, KF_A0, [&](Slab &s) {
 		KryFused a = fused_base(h, s, PH_A);
 		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
-		a.O = (L == 1 ? s.ub[1][0].p : s.ub[1][p].p);
+		a.nz = L;
+		if (L == 1) { a.Z1 = s.ub[1][p].p; a.O = s.ub[1][q].p; }
+		else { a.Z1 = s.ub[2][0].p; a.Z2 = s.ub[1][0].p; a.O = s.ub[1][1].p; }
 		return a;
 	}));
 	CHK(reduce_sums(h, PH_A));
@@ -560,7 +565,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- B (last): r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
 		CHK(stencil_step(h, KF_B0L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL1);
-			a.X = s.rb[0][p].p; a.Y = s.ub[1][0].p; a.Xout = s.rb[0][q].p;
+			a.X = s.rb[0][p].p; a.Y = s.ub[1][q].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][0].p;
 			return a;
 		}));
@@ -569,7 +574,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 		CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_B);
-			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
+			a.X = s.rb[0][p].p; a.Y = s.ub[1][1].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][p].p;
 			return a;
 		}));
@@ -577,7 +582,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 1, A: phi += alpha*u0 ; u0 = r0 - beta*u0 ; u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
 		CHK(stencil_step(h, KF_A1, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_A);
-			a.X = s.rb[1][p].p; a.Y = s.ub[1][p].p; a.Xout = s.ub[1][q].p;
+			a.X = s.rb[1][p].p; a.Y = s.ub[1][1].p; a.Xout = s.ub[1][0].p;
 			a.O = s.ub[2][0].p;
 			a.E = s.ub[0][q].p; a.Ea = s.rb[0][q].p;
 			return a;
@@ -588,7 +593,7 @@ int fused_pass(kry_solver *h, int it)
 			KryFused a = fused_base(h, s, PH_BL2);
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
 			a.O = s.rb[2][0].p;
-			a.E = s.rb[0][q].p; a.Ea = s.ub[1][q].p;
+			a.E = s.rb[0][q].p; a.Ea = s.ub[1][0].p;
 			return a;
 		}));
 		CHK(reduce_sums(h, PH_BL2));
@@ -613,14 +618,14 @@ int fused_pass(kry_solver *h, int it)
 		KryStream a = stream_base(h, s, PH_F, &nbx, &nby, 1);
 		if (L == 1) {
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][0].p;
-			a.v[2] = s.ub[0][q].p; a.v[3] = s.ub[1][0].p;
-			a.v[4] = s.rt.p;
+			a.v[2] = s.ub[0][q].p;
+			a.v[3] = s.rt.p;
 		} else {
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
-			a.v[3] = s.ub[0][q].p; a.v[4] = s.ub[1][q].p; a.v[5] = s.ub[2][0].p;
-			a.v[6] = s.rt.p;
+			a.v[3] = s.ub[0][q].p;
+			a.v[4] = s.rt.p;
 		}
-		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p; a.w[2] = s.ub[0][q].p;
+		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p;
 		HIPCHK(hipSetDevice(s.device));
 		prof_begin(h, s, 7);
 		HIPCHK(kry_launch_final(L, a, nbx, nby, s.st));
@@ -1202,8 +1207,10 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			CHK(alloc_field(s, s.Dxy));
 			CHK(alloc_field(s, s.rt));
 			for (int k = 0; k <= h->L; ++k) {
-				// vectors that feed a fused stencil after an update need a ping-pong partner
-				const int nb = (k < h->L && h->L <= 2) ? 2 : 1;
+				// vectors that feed a fused stencil after an update need a ping-pong partner;
+				// so does u1, which the first stencil kernel of a pass both reads (deferred
+				// u0 update) and produces
+				const int nb = ((k < h->L || k == 1) && h->L <= 2) ? 2 : 1;
 				for (int b = 0; b < nb; ++b) {
 					CHK(alloc_field(s, s.rb[k][b]));
 					CHK(alloc_field(s, s.ub[k][b]));
