@@ -44,10 +44,10 @@ def kernel_words(L, var, offd):
                 7: 7}              # phi,u0,r0,r1,rt -> phi,r0   (the u0 update rides in the next pass's first kernel)
     return {0: 8 + d,              # r0,u0,u1(old),u2(old),lam,rt -> u0,u1
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
-            1: 11 + d,             # r1,u1,lam,rt,phi,u0,r0 -> u1,u2,phi,u0
-            4: 8 + d,              # r1,u2,lam,r0,u1 -> r1,r2,r0
-            6: 3,                  # r2,r1,r0 -> dots only (r2' is recomputed by the last kernel)
-            7: 8}                  # phi,r0..r2,u0,rt -> phi,r0
+            1: 6 + d,              # r1,u1,lam,rt -> u1,u2
+            4: 7 + d,              # r1,u2,lam,r0,u1 -> r1,r2
+            6: 4,                  # r2,r1,r0,u1 -> dots only (r2' and r0'' are recomputed by the last kernel)
+            7: 10}                 # phi,r0..r2,u0,u1,rt -> phi,r0,u0
 
 
 def measured_traffic(kernel_name, n, L, workload, world):

@@ -49,6 +49,7 @@ struct KryOp {
 // outer iteration needs no host round trip (solveLin_BICGStab.C:317-324).
 struct KryState {
 	double rho0, rho1, alpha, beta, omega;
+	double alpha0;               // alpha of jj = 0, kept for the phi update that k_final<2> carries
 	double sigma[KRY_LMAX + 1], gammap[KRY_LMAX + 1], gamma[KRY_LMAX + 1], gammapp[KRY_LMAX + 1];
 	double tau[KRY_LMAX + 1][KRY_LMAX + 1];
 	double norm, norm_rhs, norm_init, eps;

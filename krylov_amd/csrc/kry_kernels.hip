@@ -66,6 +66,7 @@ __device__ void kry_scalar_step(KryState *S, int phase)
 		S->alpha = S->rho0 / s[0];                // :390
 		break;
 	case PH_B: {
+		S->alpha0 = S->alpha;
 		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; break; }   // :406-409
 		double rho1 = s[0];                       // :349 of the next jj
 		S->beta = S->alpha * rho1 / S->rho0;      // :351
@@ -349,7 +350,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	if (KIND != KF_SPMV && KIND != KF_RES && S->done) return;
 
 	const double cpsi = UPD ? (IS_A ? -S->beta : -S->alpha) : 0.;
-	const double alpha_prev = (KIND == KF_A1) ? S->alpha : 0.;
 	// KF_A0 first applies the u0 update that closed the previous pass
 	// (solveLin_BICGStab.C:452, 458-459): u0 -= gamma_L*u_L [; u0 -= gamma_1*u_1],
 	// so the end-of-pass kernel neither reads u_1..u_L nor writes u0.
@@ -491,43 +491,13 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		if (GEN && cstore) a.Xout[pb + coff] = psi1(sx, sy, sz1, sz2);   // sx, sy, ... still hold plane z
 	};
-	// the pointwise companions on the edge columns (GEN)
-	auto extras_col = [&](int z) {
-		if (!GEN || !cstore) return;
-		const long p = plane(z) + coff;
-		if (KIND == KF_A1) {
-			const double u0 = a.E[p], r0 = a.Ea[p];
-			a.phi[p] = axpy1(a.phi[p], u0, alpha_prev);
-			a.E[p] = axpy1(r0, u0, cpsi);
-		} else if (KIND == KF_B1L) {
-			a.E[p] = axpy1(a.E[p], a.Ea[p], cpsi);
-		}
-	};
-	// pointwise companions of plane z; returns the updated companion for dots
+	// l = 2, last B kernel: r0'' = r0' - alpha*u1 (solveLin_BICGStab.C:392-394, ii = 0 of
+	// jj = 1) enters the dot (r0'', r1) here and is formed again, with the same two
+	// roundings, by the kernels that need it later (k_mgs2, k_final); it is not stored.
 	auto extras = [&](int z, int e, double2 &comp) {
-		const long p = plane(z) + off[e];
-		if (KIND == KF_A1) {
-			// phi += u0*alpha (solveLin_BICGStab.C:403, deferred from jj = 0), then
-			// u0 = r0 - beta*u0 (:356-362, ii = 0 of jj = 1)
-			double2 u0 = ld2s(a.E + p), r0 = ld2s(a.Ea + p), ph = ld2s(a.phi + p);
-			ph = axpy2(ph, u0, alpha_prev);
-			double2 un = axpy2(r0, u0, cpsi);
-			if (urow[e]) {
-				if (uxx && uxy) { st2s(a.phi + p, ph); st2s(a.E + p, un); }
-				else if (uxx) { a.phi[p] = ph.x; a.E[p] = un.x; }
-				else if (uxy) { a.phi[p + 1] = ph.y; a.E[p + 1] = un.y; }
-			}
-			comp = un;
-		} else if (KIND == KF_B1L) {
-			// r0 -= alpha*u1 (:392-394, ii = 0 of jj = 1)
-			double2 r0 = ld2s(a.E + p), u1 = ld2s(a.Ea + p);
-			double2 rn = axpy2(r0, u1, cpsi);
-			if (urow[e]) {
-				if (uxx && uxy) st2s(a.E + p, rn);
-				else if (uxx) a.E[p] = rn.x;
-				else if (uxy) a.E[p + 1] = rn.y;
-			}
-			comp = rn;
+		if (KIND == KF_B1L) {
+			const long p = plane(z) + off[e];
+			comp = axpy2(ld2s(a.E + p), ld2s(a.Ea + p), cpsi);
 		}
 	};
 
@@ -543,11 +513,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	}
 	if (z0 == a.zlo && (GEN || g.has_lo) && z0 == 0) {   // plane -1 is a neighbour's plane or a live ghost: keep it current
 		store_psi(pm, -1);
-		if (KIND == KF_A1 || KIND == KF_B1L) {
-#pragma unroll
-			for (int e = 0; e < VD; ++e) { double2 d; extras(-1, e, d); }
-			extras_col(-1);
-		}
 	}
 	issue(z0);
 	own_psi(pc);
@@ -570,7 +535,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		// plane 0 is a domain face or counted by the lower slab; with general
 		// boundaries the face plane mz is left to k_surf as well
 		const bool cnt = (z >= 1) && (!GEN || z <= g.mz - 1 || g.has_hi);
-		if (KIND == KF_A1 || KIND == KF_B1L) extras_col(z);
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			const long p = pb + off[e];
@@ -663,14 +627,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		__syncthreads();
 	}
-	if (z1 - 1 == a.zhi && (GEN || g.has_hi) && a.zhi == g.mz) {
-		if (KIND == KF_A1 || KIND == KF_B1L) {
-#pragma unroll
-			for (int e = 0; e < VD; ++e) { double2 d; extras(g.mz + 1, e, d); }
-			extras_col(g.mz + 1);
-		}
-	}
-
 	if (KIND != KF_SPMV) {
 		KryRed r = a.red;
 		reduce_and_finalize<ND>(acc, r, a.blk_off);
@@ -758,8 +714,9 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 			acc[ND > 1 ? 1 : 0] += wgt * (o * o);
 		} else if (KIND == KF_B1L) {
 			const double r1 = a.Xout[p];
+			const double r0 = axpy1(a.E[p], a.Ea[p], -a.S->alpha);   // r0'' as in k_fused<KF_B1L>
 			acc[0] += wgt * (r1 * r1);
-			acc[ND > 1 ? 1 : 0] += wgt * (a.E[p] * r1);
+			acc[ND > 1 ? 1 : 0] += wgt * (r0 * r1);
 			acc[ND > 2 ? 2 : 0] += wgt * (o * r1);
 		}
 	}
@@ -771,10 +728,11 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 // streaming kernels of the MR part (no stencil): one block per plane segment
 // ---------------------------------------------------------------------------
 
-// l = 2 modified Gram-Schmidt step: r2' = r2 - tau12*r1 ; (r2',r2'), (r0,r2')
-// (solveLin_BICGStab.C:420-428, jj = 2).  r2' is not written back: its only other
-// use is the r0 update of k_final, which recomputes it from r2 and r1 with the
-// same two roundings, and r2 is overwritten by the next pass before any other read.
+// l = 2 modified Gram-Schmidt step: r2' = r2 - tau12*r1 ; (r2',r2'), (r0'',r2')
+// (solveLin_BICGStab.C:420-428, jj = 2) with r0'' = r0' - alpha*u1 (:392-394).
+// Neither r2' nor r0'' is written back: k_final recomputes both with the same two
+// roundings, and r2 is overwritten by the next pass before any other read.
+// v[0] = r0', v[1] = r1, v[2] = r2, v[3] = u1.
 // In-plane weights of the two values of a double2 at plane offset q (counted from
 // column QOFF of row 0): 0 off the points 0..m, 1/2 per boundary direction.
 // corner[d] tells whether the value sits on an x and a y boundary.
@@ -799,6 +757,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 	if (S->done) return;
 	constexpr int UN = SEG2 / NT;
 	const double ntau = -S->tau[1][2];
+	const double nalpha = -S->alpha;
 	double acc[2] = {0., 0.};
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
@@ -814,17 +773,18 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
 		// all loads first (reads past the end of a plane stay inside the allocation)
-		double2 r2[UN], r1[UN], r0[UN];
+		double2 r2[UN], r1[UN], r0[UN], u1[UN];
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long p = pb + q0 + 2L * i * NT;
-			r2[i] = ld2s(a.v[2] + p); r1[i] = ld2s(a.v[1] + p); r0[i] = ld2s(a.v[0] + p);
+			r2[i] = ld2s(a.v[2] + p); r1[i] = ld2s(a.v[1] + p); r0[i] = ld2s(a.v[0] + p); u1[i] = ld2s(a.v[3] + p);
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long q = q0 + 2L * i * NT;
 			if (q < a.g.ps) {
 				r2[i] = axpy2(r2[i], r1[i], ntau);   // kept in registers only: k_final recomputes it
+				r0[i] = axpy2(r0[i], u1[i], nalpha);  // r0'' = r0' - alpha*u1, likewise
 				if (GEN) {
 					if (cnt) {
 						const bool bz = (z == 0 && !a.g.has_lo) || (z == a.g.mz && !a.g.has_hi);
@@ -849,13 +809,18 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 //   dots |r0|^2 and (r0, r~).
 // The u0 updates of these lines (u0 -= gamma_L*u_L; u0 -= gamma_jj*u_jj) are left to
 // the next pass's first stencil kernel, which reads u0 anyway.
-// v[0..L] = r0..rL, v[L+1] = u0, v[L+2] = r~, w[0] = phi, w[1] = r0.
+// l = 2 also carries the pointwise statements of the second BiCG step that no
+// stencil needs (:403 of jj = 0, :356-362 with ii = 0 and :392-394 with ii = 0 of
+// jj = 1): phi += alpha0*u0; u0 = r0 - beta*u0; r0 -= alpha*u1; then :403 of jj = 1.
+// v[0..L] = r0..rL, v[L+1] = u0, v[L+2] = r~, (l = 2) v[L+3] = u1;
+// w[0] = phi, w[1] = r0, (l = 2) w[2] = u0.
 template <int L, bool GEN>
 __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 {
 	KryState *S = a.S;
 	if (S->done) return;
 	const double alpha = S->alpha;
+	const double alpha0 = S->alpha0, nbeta = -S->beta;
 	const double ntau12 = (L == 2) ? -S->tau[1][2] : 0.;
 	double g1[L + 1], gp[L + 1], gpp[L + 1];
 #pragma unroll
@@ -873,7 +838,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
-		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN];
+		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN], u1[L == 2 ? UN : 1];
 		// all loads first (reads past the end of a plane stay inside the allocation)
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
@@ -883,6 +848,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			u0[i] = ld2s(a.v[L + 1] + p);
 			ph[i] = ld2s(a.w[0] + p);
 			rt[i] = ld2s(a.v[L + 2] + p);
+			if (L == 2) u1[L == 2 ? i : 0] = ld2s(a.v[L + 3] + p);
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
@@ -890,7 +856,14 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			if (q < a.g.ps) {
 				const long p = pb + q;
 				if (L == 2) r[i][2] = axpy2(r[i][2], r[i][1], ntau12);   // the Gram-Schmidt step of k_mgs2
-				double2 phv = axpy2(ph[i], u0[i], alpha);
+				double2 phv = ph[i];
+				if (L == 2) {
+					phv = axpy2(phv, u0[i], alpha0);                       // phi += alpha0*u0
+					u0[i] = axpy2(r[i][0], u0[i], nbeta);                  // u0 = r0' - beta*u0
+					r[i][0] = axpy2(r[i][0], u1[L == 2 ? i : 0], -alpha);  // r0'' = r0' - alpha*u1
+					st2s(a.w[2] + p, u0[i]);
+				}
+				phv = axpy2(phv, u0[i], alpha);
 				phv = axpy2(phv, r[i][0], g1[1]);
 				double2 r0 = axpy2(r[i][0], r[i][L], -gp[L]);
 #pragma unroll

@@ -579,16 +579,15 @@ int fused_pass(kry_solver *h, int it)
 			return a;
 		}));
 		CHK(reduce_sums(h, PH_B));
-		// --- jj = 1, A: phi += alpha*u0 ; u0 = r0 - beta*u0 ; u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
+		// --- jj = 1, A: u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
 		CHK(stencil_step(h, KF_A1, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_A);
 			a.X = s.rb[1][p].p; a.Y = s.ub[1][1].p; a.Xout = s.ub[1][0].p;
 			a.O = s.ub[2][0].p;
-			a.E = s.ub[0][q].p; a.Ea = s.rb[0][q].p;
 			return a;
 		}));
 		CHK(reduce_sums(h, PH_A));
-		// --- jj = 1, B (last): r0 -= alpha*u1 ; r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0,r1), (r2,r1)
+		// --- jj = 1, B (last): r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0 - alpha*u1, r1), (r2,r1)
 		CHK(stencil_step(h, KF_B1L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL2);
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
@@ -601,7 +600,7 @@ int fused_pass(kry_solver *h, int it)
 		CHK(for_slabs([&](Slab &s, int) -> int {
 			int nbx, nby;
 			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby, 4);
-			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
+			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p; a.v[3] = s.ub[1][0].p;
 			a.w[0] = s.rb[2][0].p;
 			HIPCHK(hipSetDevice(s.device));
 			prof_begin(h, s, 6);
@@ -612,7 +611,7 @@ int fused_pass(kry_solver *h, int it)
 		CHK(reduce_sums(h, PH_M2));
 	}
 
-	// --- end of pass: phi, r0, u0 updates ; |r0|^2, (r0, r~)
+	// --- end of pass: phi and r0 updates (l = 2: also the pointwise statements of jj = 1) ; |r0|^2, (r0, r~)
 	CHK(for_slabs([&](Slab &s, int) -> int {
 		int nbx, nby;
 		KryStream a = stream_base(h, s, PH_F, &nbx, &nby, 1);
@@ -624,6 +623,8 @@ int fused_pass(kry_solver *h, int it)
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
 			a.v[3] = s.ub[0][q].p;
 			a.v[4] = s.rt.p;
+			a.v[5] = s.ub[1][0].p;
+			a.w[2] = s.ub[0][q].p;
 		}
 		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p;
 		HIPCHK(hipSetDevice(s.device));
