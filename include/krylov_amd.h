@@ -105,6 +105,12 @@ int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks);
  * (No counterpart in the reference; a deployment check.) */
 int kry_comm_selftest(int device);
 
+/* KRY_OK when HIP device `device` exists and accepts work (a small allocation and
+ * copy are tried), else KRY_ERR_HIP with kry_last_error() set.  Stands in for the
+ * context set-up of the reference's OpenCL solver (BiCGStabSolver::setupContext,
+ * BiCGStab3D_CL/BiCGStabCL.hpp:130-131), which fails there when the device is unusable. */
+int kry_device_check(int device);
+
 /* The same role with the caller's own transport instead of RCCL, e.g. the
  * MPI communicator of a `-D parallel` build (the reference exchanges faces with
  * MPI_Isend/MPI_Irecv, BICGStab3D/BoundaryHandler.C:1633-1677, and reduces with
@@ -156,6 +162,13 @@ int kry_fetch_phi(kry_handle h, double *phi);
 int kry_get_stats(kry_handle h, kry_stats *out);
 /* `norm` of every outer iteration (solveLin_BICGStab.C:464); returns the count. */
 int kry_get_history(kry_handle h, double *norms, int cap);
+
+/* Wall-clock milliseconds of every outer iteration since the last load, the data
+ * behind BiCGStabSolver::stepRuntimes / steptimeMin / steptimeMax of the reference's
+ * OpenCL solver (BiCGStab3D_CL/BiCGStabCL.hpp:137-143, 196-200).  The fused paths
+ * run iterations in batches without a host round trip; a batch's time is spread
+ * evenly over its iterations.  Returns the count. */
+int kry_get_step_times(kry_handle h, double *ms, int cap);
 
 /* Single operators on host fields, for kernel-level checks.  They run the same
  * device kernels the solver uses.

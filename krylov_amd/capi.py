@@ -21,10 +21,10 @@ STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reache
 
 # every symbol include/krylov_amd.h declares
 SYMBOLS = [
-    "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks",
+    "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks", "kry_device_check",
     "kry_comm_selftest", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
-    "kry_get_stats", "kry_get_history", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
+    "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
 ]
 

@@ -3,6 +3,7 @@
 // host arrays, the BICGStab adaptor).
 #include <cstring>
 
+#include "BiCGStabCL.hpp"
 #include "BoundaryHandler.H"
 #include "grid_manager.H"
 #include "solveLin_BICGStab.H"
@@ -74,6 +75,37 @@ int compat_solve(const int mx[3], const int bc[6], int L, double eps, int max_it
 	for (int i = 0; i < (int)h.size() && i < hist_cap; ++i) hist[i] = h[i];
 	*fused = s.usedFusedKernels() ? 1 : 0;
 	return s.iterations();
+}
+
+// the construction style of the reference's OpenCL solver (BiCGStab3D_CL/main.cpp:410-412, 532-540):
+// constant-coefficient solve on Dirichlet faces; out = {iterations, steptimeMin, steptimeMax, number of step times,
+// sum of the unrounded step times in ms}
+int compat_solve_cl_style(int m, int L, double eps, const double Dc[3], double *phi, const double *rhs, const double *lam,
+                          double out[5])
+{
+	const int mx[3] = {m, m, m};
+	grid_manager grid(0., 0., 0., 1., 1., 1., m + 1, m + 1, m + 1, 1);
+	BoundaryHandler3D b;
+	b.set_bcType(0);
+	NumMatrix<double, 3> mphi, mrhs, mlam;
+	wrap(mphi, mx, phi); wrap(mrhs, mx, rhs); wrap(mlam, mx, lam);
+	BiCGStabSolver solver(grid, eps, L, 0);
+	solver.setVerbose(false);
+	if (solver.isInitialized()) return -1;
+	solver.setupContext();
+	if (!solver.isInitialized()) return -2;
+	solver.solve(b, mphi, mrhs, mlam, Dc[0], Dc[1], Dc[2], 0);
+	memcpy(phi, mphi.data(), mphi.size() * sizeof(double));
+	std::vector<long> t = solver.stepRuntimes();
+	std::vector<double> tm = solver.stepRuntimesMs();
+	out[0] = (double)solver.iterations();
+	out[1] = (double)solver.steptimeMin();
+	out[2] = (double)solver.steptimeMax();
+	out[3] = (double)t.size();
+	out[4] = 0.;
+	for (size_t i = 0; i < tm.size(); ++i) out[4] += tm[i];
+	solver.cleanupContext();
+	return solver.isInitialized() ? -3 : 0;
 }
 
 }

@@ -223,6 +223,17 @@ std::vector<double> BICGStab::residualHistory() const
 	return h;
 }
 
+std::vector<double> BICGStab::step_times() const
+{
+	std::vector<double> t;
+	if (!handle) return t;
+	int n = kry_get_step_times(handle, NULL, 0);
+	if (n <= 0) return t;
+	t.resize(n);
+	kry_get_step_times(handle, t.data(), n);
+	return t;
+}
+
 void BICGStab::solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
                      NumMatrix<double, 3> &lambda, double D_xx, double D_yy, double D_zz, int debug_, double, bool)
 {

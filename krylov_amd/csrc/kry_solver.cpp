@@ -113,6 +113,7 @@ struct kry_solver {
 	double solve_ms = 0, stage_ms = 0;
 	double enqueue_ms = 0;     // host time spent queueing the passes of the last run
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
+	std::vector<double> step_ms;   // wall time per pass (a batch's time spread evenly over its passes)
 	bool profile = false;
 	bool overlap = true;       // halo exchange concurrent with the interior chunks
 	Prof prof;
@@ -897,6 +898,7 @@ int prologue(kry_solver *h)
 	h->status = 0;
 	h->done = false;
 	h->hist.clear();
+	h->step_ms.clear();
 	h->g_rho0 = 1.; h->g_alpha = 0.; h->g_omega = 1.;
 
 	// the reference allocates zeroed work vectors once (make_Arrays) and starts
@@ -1027,6 +1029,11 @@ int run_iterations(kry_solver *h, int n_outer)
 			for (int i = 0; i < nb; ++i) CHK(fused_pass(h, it0 + i));
 			h->enqueue_ms += now_ms() - t0;
 			CHK(poll_state(h));
+			{
+				const int ran = std::max(1, h->it_base - it0);
+				const double each = (now_ms() - t0) / ran;
+				for (int i = 0; i < h->it_base - it0; ++i) h->step_ms.push_back(each);
+			}
 			if (h->debug > 2) {
 				Slab &s = h->slabs[0];
 				(void)s;
@@ -1047,6 +1054,7 @@ int run_iterations(kry_solver *h, int n_outer)
 		while (!h->done && (n_outer <= 0 || left > 0)) {
 			double t0 = now_ms();
 			CHK(generic_pass(h, sigma, gammap, gamma, gammapp, tau));
+			h->step_ms.push_back(now_ms() - t0);
 			if (h->debug > 2) {
 				printf(" Iteration: %d (%.3f ms)\n", h->it_base, now_ms() - t0);
 				printf(" My error norm: %g %g %g %g %g \n", h->norm_final, std::sqrt(h->norm_final),
@@ -1309,6 +1317,20 @@ int kry_comm_selftest(int device)
 	return st;
 }
 
+int kry_device_check(int device)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err("no HIP device available"); return KRY_ERR_HIP; }
+	if (device < 0 || device >= ndev) { set_err("device %d out of range (have %d)", device, ndev); return KRY_ERR_HIP; }
+	double *d = nullptr, v = 42., w = 0.;
+	bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void **)&d, sizeof(double)) == hipSuccess &&
+	          hipMemcpy(d, &v, sizeof v, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(&w, d, sizeof w, hipMemcpyDeviceToHost) == hipSuccess && w == v;
+	if (d) hipFree(d);
+	if (!ok) { set_err("device %d does not accept work", device); return KRY_ERR_HIP; }
+	return KRY_OK;
+}
+
 int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
                             void *ctx)
 {
@@ -1449,6 +1471,14 @@ int kry_get_history(kry_handle h, double *norms, int cap)
 	}
 	n = (int)h->hist.size();
 	for (int i = 0; i < std::min(n, cap); ++i) norms[i] = h->hist[i];
+	return n;
+}
+
+int kry_get_step_times(kry_handle h, double *ms, int cap)
+{
+	if (!h || (!ms && cap > 0)) return KRY_ERR_ARG;
+	const int n = (int)h->step_ms.size();
+	for (int i = 0; i < std::min(n, cap); ++i) ms[i] = h->step_ms[i];
 	return n;
 }
 

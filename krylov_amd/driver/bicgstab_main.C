@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../compat/BoundaryHandler.H"
 #include "../compat/LinSolver3D.hpp"
@@ -252,11 +253,22 @@ int main(int argc, char *argv[])
 		// columns of the reference's --stats row (BiCGStab3D_CL/main.cpp:576,600-602)
 		const int it = bs->iterations();
 		const double calc = bs->solveRuntime();
-		const double avg = it > 0 ? calc / it : 0.;
+		const std::vector<double> steps = bs->step_times();
+		double tmin = 0., tmax = 0., avg = it > 0 ? calc / it : 0., geo = avg;
+		if (!steps.empty()) {
+			tmin = tmax = steps[0];
+			double sum = 0., logsum = 0.;
+			for (size_t i = 0; i < steps.size(); ++i) {
+				tmin = min(tmin, steps[i]); tmax = max(tmax, steps[i]);
+				sum += steps[i]; logsum += log(max(steps[i], 1e-300));
+			}
+			avg = sum / steps.size();
+			geo = exp(logsum / steps.size());
+		}
 		cout << "# Test, Size, Iterations, Total runtime, Calculation time, Min step time, Max step time, "
 		        "Average (arithmetic), Average (geometric), Tolerance, L2 error, Max error" << endl;
-		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, opt.mx, it, runtime, calc, avg,
-		       avg, avg, avg, opt.tol, l2err, emax);
+		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, opt.mx, it, runtime, calc, tmin,
+		       tmax, avg, geo, opt.tol, l2err, emax);
 	} else {
 		cout << " l2 error for " << opt.mx << " is " << l2err << endl;
 		cout << "Runtime (solver) : " << (long long)runtime << " ms" << endl;

@@ -123,3 +123,20 @@ def test_parallel_driver_under_mpi(test, nproc):
     ia = int(re.search(r"Iterations\s*:\s*(\d+)", serial.stdout).group(1))
     ib = int(re.search(r"Iterations\s*:\s*(\d+)", par.stdout).group(1))
     assert abs(ia - ib) <= max(6, ia // 3)
+
+
+def test_opencl_solver_style_class():
+    """BiCGStabSolver(grid, tol, l, device) + setupContext / iterations / stepRuntimes /
+    steptimeMin / steptimeMax, the calling sequence of BiCGStab3D_CL/main.cpp:410-412, 532-540."""
+    lib = C.CDLL(os.path.join(ROOT, "krylov_amd", "libkrylov_compat_test.so"))
+    p = P.reference_test1(32)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    lib.compat_solve_cl_style.restype = C.c_int
+    lib.compat_solve_cl_style.argtypes = [C.c_int, C.c_int, C.c_double, dp, dp, dp, dp, dp]
+    phi, out = p.phi.copy(), np.zeros(5)
+    rc = lib.compat_solve_cl_style(32, 2, 1e-6, np.array(p.Dc, dtype=np.float64), phi, p.rhs.copy(), p.lam.copy(), out)
+    assert rc == 0
+    ref = capi.solve_problem(p, L=2, eps=1e-6)
+    assert int(out[0]) == ref["iters"] and int(out[3]) == ref["iters"]
+    assert np.array_equal(phi, ref["phi"])
+    assert 0 <= out[1] <= out[2] and out[4] > 0.
