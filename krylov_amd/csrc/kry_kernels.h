@@ -74,6 +74,7 @@ hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStre
 hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st);
 hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, hipStream_t st);
 hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st);
+hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int px, bool to_device, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,

@@ -906,6 +906,19 @@ __global__ __launch_bounds__(NT) void g_axpy(double *dst, const double *x, const
 		st2(dst + 2 * q, axpy2(ld2(x + 2 * q), ld2(y + 2 * q), c));
 }
 
+// Host layout (rows of `w` doubles, no padding) <-> device layout (row pitch px,
+// first value of a row in column 1).  One wave per row.
+__global__ __launch_bounds__(NT) void g_repack(double *dev, double *packed, int w, long rows, int px, int to_device)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (long r = (long)blockIdx.x * NW + wv; r < rows; r += (long)gridDim.x * NW) {
+		double *d = dev + r * px + 1;
+		double *p = packed + r * w;
+		if (to_device) for (int i = lane; i < w; i += 64) d[i] = p[i];
+		else for (int i = lane; i < w; i += 64) p[i] = d[i];
+	}
+}
+
 // dst = a - b (Krylov.C:259)
 __global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const double *y, long n2)
 {
@@ -1144,6 +1157,13 @@ hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double
 {
 	const long n2 = n / 2;
 	hipLaunchKernelGGL(g_axpy, dim3(min(cdiv(n2, NT), 8192)), dim3(NT), 0, st, dst, x, y, c, n2);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int px, bool to_device, hipStream_t st)
+{
+	hipLaunchKernelGGL(g_repack, dim3((unsigned)std::min<long>((rows + NW - 1) / NW, 32768)), dim3(NT), 0, st, dev, packed, w,
+	                   rows, px, to_device ? 1 : 0);
 	return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ struct Slab {
 	long partial_cap = 0;
 	unsigned *counter = nullptr;
 	double *gather = nullptr;  // slab_count * KRY_NSUMS doubles (used on the first slab)
+	double *stage = nullptr;   // device staging buffer of the host<->device copies (freed after use)
+	size_t stage_cap = 0;
 	std::vector<Field *> all;
 };
 
@@ -151,6 +153,28 @@ void free_fields(Slab &s)
 }
 
 // host box <-> device box.  Host planes of the slab start at k_host = index_local*mzl.
+// The host block of a slab is contiguous; it crosses PCIe as one linear copy into /
+// out of a device staging buffer and is re-pitched by a kernel (a pitched 2D copy
+// from pageable memory moves row by row and is an order of magnitude slower).
+int ensure_stage(Slab &s, size_t doubles)
+{
+	if (s.stage_cap >= doubles) return 0;
+	HIPCHK(hipSetDevice(s.device));
+	if (s.stage) HIPCHK(hipFree(s.stage));
+	s.stage = nullptr;
+	s.stage_cap = 0;
+	HIPCHK(hipMalloc((void **)&s.stage, doubles * sizeof(double)));
+	s.stage_cap = doubles;
+	return 0;
+}
+
+void drop_stage(Slab &s)
+{
+	if (s.stage) { hipSetDevice(s.device); hipFree(s.stage); }
+	s.stage = nullptr;
+	s.stage_cap = 0;
+}
+
 int upload(kry_solver *h, Slab &s, int local_idx, Field &f, const double *host)
 {
 	HIPCHK(hipSetDevice(s.device));
@@ -158,8 +182,9 @@ int upload(kry_solver *h, Slab &s, int local_idx, Field &f, const double *host)
 	const size_t hrow = (size_t)(mxh + 3);
 	const double *src = host + (size_t)local_idx * h->mzl * hrow * (myh + 3);
 	const size_t rows = (size_t)(myh + 3) * (s.g.mz + 3);
-	HIPCHK(hipMemcpy2DAsync(f.p + 1, (size_t)s.g.px * sizeof(double), src, hrow * sizeof(double),
-	                        hrow * sizeof(double), rows, hipMemcpyHostToDevice, s.st));
+	CHK(ensure_stage(s, rows * hrow));
+	HIPCHK(hipMemcpyAsync(s.stage, src, rows * hrow * sizeof(double), hipMemcpyDefault, s.st));
+	HIPCHK(kry_launch_repack(f.p, s.stage, (int)hrow, (long)rows, s.g.px, true, s.st));
 	return 0;
 }
 
@@ -173,10 +198,11 @@ int download(kry_solver *h, Slab &s, int local_idx, const Field &f, double *host
 	int k0 = (local_idx == 0) ? -1 : 0;
 	int k1 = (local_idx == (int)h->slabs.size() - 1) ? s.g.mz + 1 : s.g.mz;
 	double *dst = host + ((size_t)local_idx * h->mzl + (k0 + 1)) * hplane;
-	const double *src = f.p + 1 + (long)(k0 + 1) * s.g.ps;
+	double *src = f.p + (long)(k0 + 1) * s.g.ps;
 	const size_t rows = (size_t)(myh + 3) * (k1 - k0 + 1);
-	HIPCHK(hipMemcpy2DAsync(dst, hrow * sizeof(double), src, (size_t)s.g.px * sizeof(double),
-	                        hrow * sizeof(double), rows, hipMemcpyDeviceToHost, s.st));
+	CHK(ensure_stage(s, rows * hrow));
+	HIPCHK(kry_launch_repack(src, s.stage, (int)hrow, (long)rows, s.g.px, false, s.st));
+	HIPCHK(hipMemcpyAsync(dst, s.stage, rows * hrow * sizeof(double), hipMemcpyDefault, s.st));
 	return 0;
 }
 
@@ -1112,6 +1138,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	h->enqueue_ms = 0;
 	CHK(prologue(h));
 	CHK(sync_all(h));
+	for (Slab &s : h->slabs) drop_stage(s);
 	h->stage_ms = now_ms() - t0;
 	return h->status;
 }
@@ -1121,6 +1148,7 @@ int finish_solve(kry_solver *h, double *phi)
 	double t0 = now_ms();
 	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(download(h, h->slabs[i], (int)i, h->slabs[i].phi, phi));
 	CHK(sync_all(h));
+	for (Slab &s : h->slabs) drop_stage(s);
 	h->stage_ms += now_ms() - t0;
 	return 0;
 }
@@ -1277,6 +1305,7 @@ void kry_destroy(kry_handle h)
 		if (s.partial) hipFree(s.partial);
 		if (s.counter) hipFree(s.counter);
 		if (s.gather) hipFree(s.gather);
+		if (s.stage) hipFree(s.stage);
 		if (s.ev) hipEventDestroy(s.ev);
 		if (s.ev_in) hipEventDestroy(s.ev_in);
 		if (s.ev_edge) hipEventDestroy(s.ev_edge);
