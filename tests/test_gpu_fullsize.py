@@ -1,5 +1,7 @@
-"""Full-size checks at 256^3 (the single-GPU size of the benchmark configs),
-where the CPU oracle would take minutes: size-independent properties only."""
+"""Full-size checks at 256^3, 512^3 and on the 1024 x 1024 x 128 block (the sizes of
+the benchmark configs), where the CPU oracle would take minutes to hours:
+size-independent properties and cross-checks between the library's two device
+implementations only."""
 import numpy as np
 import pytest
 
@@ -79,3 +81,24 @@ def test_weak_scaling_block_shape_1024x1024x128():
         assert s.iterate(5) == 0
         h = s.history()
     assert len(h) == 5 and np.all(np.isfinite(h)) and h[-1] < h[0]
+
+
+@pytest.mark.parametrize("workload,passes,tol", [("var", 3, 1e-9), ("mixed", 2, 1e-9)])
+def test_benchmark_grid_512_fused_against_one_kernel_per_primitive(workload, passes, tol):
+    """The benchmark's 512^3 problems: the fused kernels (Dirichlet faces / mixed
+    faces) against the library's other device implementation, which evaluates the
+    reference's statements one kernel at a time.  The two differ in the summation
+    order of the dot products only, so the first passes agree to rounding noise
+    (later passes separate chaotically, on the high-contrast problem quickly)."""
+    import bench
+    f = bench.slab_problem(512, 1, 0, workload)
+    hist = []
+    for flags, path in ((0, 1 if workload == "var" else 2), (capi.KRY_FORCE_GENERIC, 0)):
+        with capi.Solver(f["mx"], f["delx"], f["bc"], L=2, eps=0.0, flags=flags) as s:
+            s.load_var(f["phi"], f["rhs"], f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False)
+            assert s.iterate(passes) == 0
+            assert s.stats().fused == path
+            hist.append(s.history())
+    a, b = hist
+    assert len(a) == len(b) == passes
+    assert np.max(np.abs(a - b) / np.abs(b)) <= tol
