@@ -7,8 +7,10 @@
  * Host field layout (what the reference's NumMatrix<double,3> fields hold):
  * ghost-inclusive box [-1 .. m+1] per direction, x fastest, no padding:
  *   index(i,j,k) = ((k+1)*(my+3) + (j+1))*(mx+3) + (i+1).
- * The library copies host fields into its own padded device layout and never
- * keeps a host pointer after a call returns.
+ * The library copies the fields into its own padded device layout and never
+ * keeps a caller's pointer after a call returns.  Every field argument may be a
+ * host pointer or a device pointer (same layout): a caller whose fields already
+ * live on the GPU pays no PCIe transfer.
  *
  * Domain decomposition: z slabs that share their interface plane, as
  * mpi_manager_3D::make_LocalGrid does for direction 2

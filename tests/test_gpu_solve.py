@@ -124,3 +124,35 @@ def test_zero_rhs_no_iterations(orc):
     p.rhs[:] = 0
     want, got = compare(orc, p, 2)
     assert got["iters"] == 0
+
+
+def test_fields_may_live_in_device_memory(orc):
+    """The field arguments of the C ABI may be device pointers (same unpadded
+    layout): a caller that keeps its fields on the GPU pays no PCIe transfer."""
+    import ctypes as C
+    L = capi.lib()
+    p = P.smooth_var(32)
+    ref = capi.solve_problem(p, L=2, eps=1e-6)
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipFree.argtypes = [C.c_void_p]
+    raw = C.CFUNCTYPE(C.c_int, C.c_void_p, *([C.c_void_p] * 7), C.c_int, C.c_int)(("kry_solve_var", L))
+    dev = []
+
+    def to_device(a):
+        d = C.c_void_p()
+        assert L.hipMalloc(C.byref(d), a.nbytes) == 0
+        assert L.hipMemcpy(d, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+        dev.append(d)
+        return d
+
+    with capi.Solver(p.mx, p.delx, p.bc, L=2, eps=1e-6) as s:
+        args = [to_device(np.ascontiguousarray(a)) for a in (p.phi, p.rhs, p.lam, p.Dxx, p.Dyy, p.Dzz)]
+        st = raw(s._h, *args, None, 0, 0)
+        assert st == 0
+        phi = np.empty_like(p.phi)
+        assert L.hipMemcpy(phi.ctypes.data_as(C.c_void_p), args[0], phi.nbytes, 2) == 0
+        assert np.array_equal(s.history(), ref["history"])
+    for d in dev:
+        L.hipFree(d)
+    assert np.array_equal(phi, ref["phi"])
