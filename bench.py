@@ -199,6 +199,7 @@ def main():
     # torch.distributed afterwards and for the control plane only
     from krylov_amd import capi
     capi.lib()
+    capi.device_check(int(os.environ.get("KRY_BENCH_DEVICE", local_rank)))
 
     dist = None
     if world > 1:

@@ -145,6 +145,11 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def device_check(device=0):
+    """Raises KryError unless HIP device `device` accepts work from this library."""
+    return _check(lib().kry_device_check(int(device)), "kry_device_check")
+
+
 def comm_selftest(device=0):
     return _check(lib().kry_comm_selftest(int(device)), "kry_comm_selftest")
 

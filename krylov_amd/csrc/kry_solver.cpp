@@ -1155,6 +1155,17 @@ int finish_solve(kry_solver *h, double *phi)
 
 } // namespace
 
+// A process may hold a second copy of the HIP runtime (a Python package that bundles
+// its own): whichever copy touches the GPU first must be this library's, or this
+// one's later initialisation fails.  Initialising when the library is loaded makes
+// "load this library first" sufficient.
+__attribute__((constructor)) static void kry_runtime_init()
+{
+	int n = 0;
+	(void)hipGetDeviceCount(&n);
+	(void)hipGetLastError();
+}
+
 // ===================================================================== C ABI
 
 extern "C" {
