@@ -12,7 +12,8 @@
  * host pointer or a device pointer (same layout): a caller whose fields already
  * live on the GPU pays no PCIe transfer.
  *
- * Domain decomposition: z slabs that share their interface plane, as
+ * Domain decomposition: sub-domains that share their interface planes, by default
+ * z slabs (a Cartesian split in all three directions: kry_desc.nproc), as
  * mpi_manager_3D::make_LocalGrid does for direction 2
  * (BICGStab3D/mpi_manager.C:342-408): with `nslabs` slabs every slab has
  * mz_local = mz_global / nslabs and plane mz_local of slab s is plane 0 of
@@ -64,6 +65,15 @@ typedef struct kry_desc {
 	int    slab_begin;     /* first slab owned by this process */
 	int    slab_count;     /* slabs owned by this process (>= 1) */
 	int    devices[KRY_MAX_SLABS]; /* HIP device ordinal per owned slab */
+	/* Optional Cartesian split over processes, the layout of mpi_manager_3D
+	 * (BICGStab3D/mpi_manager.C:56-305, 342-408): nproc sub-domains per direction, this
+	 * process at coord, rank = (coord[0]*nproc[1] + coord[1])*nproc[2] + coord[2]
+	 * (MPI_Cart_create without reordering).  All zero: plain z slabs as described by
+	 * nslabs / slab_begin / slab_count.  Otherwise one sub-domain per process
+	 * (slab_count = 1), mx[] are the LOCAL extents (global / nproc) and a communicator
+	 * (kry_comm_init*) over nproc[0]*nproc[1]*nproc[2] ranks is required. */
+	int    nproc[3];
+	int    coord[3];
 } kry_desc;
 
 typedef struct kry_stats {

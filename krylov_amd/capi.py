@@ -42,6 +42,8 @@ class KryDesc(C.Structure):
         ("slab_begin", C.c_int),
         ("slab_count", C.c_int),
         ("devices", C.c_int * KRY_MAX_SLABS),
+        ("nproc", C.c_int * 3),
+        ("coord", C.c_int * 3),
     ]
 
 
@@ -165,7 +167,7 @@ class Solver:
     passes (its own slabs only)."""
 
     def __init__(self, mx, delx, bc=(0,) * 6, L=2, eps=1e-6, max_outer=0, flags=0,
-                 nslabs=1, slab_begin=0, slab_count=1, devices=(0,)):
+                 nslabs=1, slab_begin=0, slab_count=1, devices=(0,), nproc=None, coord=None):
         d = KryDesc()
         for k in range(3):
             d.mx[k] = int(mx[k])
@@ -177,6 +179,10 @@ class Solver:
         devs = list(devices) + [devices[-1]] * (slab_count - len(devices))
         for i in range(slab_count):
             d.devices[i] = int(devs[i])
+        if nproc is not None:            # Cartesian split: this process holds sub-domain `coord`
+            for k in range(3):
+                d.nproc[k], d.coord[k] = int(nproc[k]), int(coord[k])
+            d.nslabs, d.slab_begin = int(nproc[2]), int(coord[2])
         st = C.c_int(0)
         self._h = lib().kry_create(C.byref(d), C.byref(st))
         if not self._h:

@@ -20,7 +20,7 @@ BICGStab::BICGStab()
 	for (int f = 0; f < 6; ++f) handle_bc[f] = -99;
 #ifdef parallel
 	comm3d = MPI_COMM_NULL;
-	nslabs_mpi = 1; slab_mpi = 0; nb_lo = nb_hi = MPI_PROC_NULL;
+	for (int d = 0; d < 3; ++d) { nproc_mpi[d] = 1; coord_mpi[d] = 0; }
 #endif
 	devices.push_back(0);
 	// KRY_DEVICES=0,1,2,... : one z slab per listed device
@@ -63,22 +63,13 @@ void BICGStab::release()
 }
 
 #ifdef parallel
-// The device solver splits the domain along z only (BICGStab3D/solveLin_BICGStab.C:
-// 142-147 takes comm3d and the rank from the manager).
+// BICGStab3D/solveLin_BICGStab.C:142-147 takes comm3d and the rank from the manager;
+// here its split and this process's place in it are kept as well.
 void BICGStab::use_MPI(mpi_manager_3D &MyMPI)
 {
 	comm3d = MyMPI.comm3d;
 	rank = MyMPI.get_rank();
-	if (MyMPI.get_nproc(0) != 1 || MyMPI.get_nproc(1) != 1) {
-		if (rank == 0)
-			cerr << " BICGStab: the device solver decomposes along z only; use nproc = {1, 1, P} instead of {"
-			     << MyMPI.get_nproc(0) << ", " << MyMPI.get_nproc(1) << ", " << MyMPI.get_nproc(2) << "}" << endl;
-		MyMPI.Finalise();
-	}
-	nslabs_mpi = MyMPI.get_nproc(2);
-	slab_mpi = MyMPI.get_coord(2);
-	nb_lo = MyMPI.get_bottom();
-	nb_hi = MyMPI.get_top();
+	for (int d = 0; d < 3; ++d) { nproc_mpi[d] = MyMPI.get_nproc(d); coord_mpi[d] = MyMPI.get_coord(d); }
 }
 
 int BICGStab::mpi_allreduce(void *ctx, double *buf, int n)
@@ -88,15 +79,17 @@ int BICGStab::mpi_allreduce(void *ctx, double *buf, int n)
 	return MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, MPI_SUM, self->comm3d) == MPI_SUCCESS ? 0 : 1;
 }
 
-int BICGStab::mpi_halo(void *ctx, int, const double *send_lo, double *recv_lo, int, const double *send_hi,
-                       double *recv_hi, unsigned long count)
+int BICGStab::mpi_halo(void *ctx, int peer_lo, const double *send_lo, double *recv_lo, int peer_hi,
+                       const double *send_hi, double *recv_hi, unsigned long count)
 {
-	// BoundaryHandler.C:1633-1677 for direction 2
+	// BoundaryHandler.C:1633-1677; the library names the neighbours by their rank in the
+	// Cartesian communicator (no reordering), a negative rank meaning "none"
 	BICGStab *self = static_cast<BICGStab *>(ctx);
-	int e1 = MPI_Sendrecv(send_lo, (int)count, MPI_DOUBLE, self->nb_lo, 81, recv_hi, (int)count, MPI_DOUBLE, self->nb_hi,
-	                      81, self->comm3d, MPI_STATUS_IGNORE);
-	int e2 = MPI_Sendrecv(send_hi, (int)count, MPI_DOUBLE, self->nb_hi, 82, recv_lo, (int)count, MPI_DOUBLE, self->nb_lo,
-	                      82, self->comm3d, MPI_STATUS_IGNORE);
+	const int lo = peer_lo < 0 ? MPI_PROC_NULL : peer_lo, hi = peer_hi < 0 ? MPI_PROC_NULL : peer_hi;
+	int e1 = MPI_Sendrecv(send_lo, (int)count, MPI_DOUBLE, lo, 81, recv_hi, (int)count, MPI_DOUBLE, hi, 81, self->comm3d,
+	                      MPI_STATUS_IGNORE);
+	int e2 = MPI_Sendrecv(send_hi, (int)count, MPI_DOUBLE, hi, 82, recv_lo, (int)count, MPI_DOUBLE, lo, 82, self->comm3d,
+	                      MPI_STATUS_IGNORE);
 	return (e1 == MPI_SUCCESS && e2 == MPI_SUCCESS) ? 0 : 1;
 }
 
@@ -158,11 +151,12 @@ void BICGStab::ensure_handle(BoundaryHandler3D &bounds, const NumMatrix<double, 
 	d.eps = eps;
 	d.max_outer = max_outer;
 #ifdef parallel
-	// one slab per process; process r uses the (r mod listed)-th listed device
-	d.nslabs = nslabs_mpi;
-	d.slab_begin = slab_mpi;
+	// one sub-domain per process; process r uses the (r mod listed)-th listed device
+	for (int k = 0; k < 3; ++k) { d.nproc[k] = nproc_mpi[k]; d.coord[k] = coord_mpi[k]; }
+	d.nslabs = nproc_mpi[2];
+	d.slab_begin = coord_mpi[2];
 	d.slab_count = 1;
-	d.devices[0] = devices[slab_mpi % devices.size()];
+	d.devices[0] = devices[rank % devices.size()];
 #else
 	int ns = (int)devices.size();
 	while (ns > 1 && (mx[2] % ns != 0 || mx[2] / ns < 4)) --ns;
@@ -178,8 +172,9 @@ void BICGStab::ensure_handle(BoundaryHandler3D &bounds, const NumMatrix<double, 
 		exit(2);
 	}
 #ifdef parallel
-	if (nslabs_mpi > 1 &&
-	    kry_comm_init_host_callbacks(handle, slab_mpi, nslabs_mpi, &BICGStab::mpi_allreduce, &BICGStab::mpi_halo, this) != 0) {
+	const int ntasks_mpi = nproc_mpi[0] * nproc_mpi[1] * nproc_mpi[2];
+	if (ntasks_mpi > 1 &&
+	    kry_comm_init_host_callbacks(handle, rank, ntasks_mpi, &BICGStab::mpi_allreduce, &BICGStab::mpi_halo, this) != 0) {
 		cerr << " BICGStab: cannot attach the MPI transport (" << kry_last_error() << ")" << endl;
 		exit(2);
 	}

@@ -27,6 +27,11 @@ struct KryGeo {
 	// position of this slab in the global domain (z slabs)
 	int has_lo;         // 1: plane -1 is a neighbour's plane (not a domain face)
 	int has_hi;         // 1: plane mz+1 is a neighbour's plane
+	int nb[6];          // per face xlo,xhi,ylo,yhi,zlo,zhi: 1 = a neighbouring sub-domain lies behind it
+	                    // (nb[4] == has_lo, nb[5] == has_hi).  Interface planes are held by both
+	                    // sides; in dot products they count once: z and y interfaces on the lower
+	                    // side, x interfaces on the upper side (which also evaluates the operator
+	                    // there; the lower side receives plane mx with the halo exchange).
 	int bc[6];          // face types of the GLOBAL domain
 };
 

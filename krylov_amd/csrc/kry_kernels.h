@@ -67,7 +67,7 @@ struct KryStream {
 
 hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact,
                             hipStream_t st);
-hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool offd, bool exact, hipStream_t st);
+hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, hipStream_t st);
 hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st);
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);
 hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st);
@@ -75,6 +75,7 @@ hipError_t kry_launch_scalar(KryState *S, int phase, hipStream_t st);
 hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, hipStream_t st);
 hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st);
 hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int px, bool to_device, hipStream_t st);
+hipError_t kry_launch_face(double *field, double *buf, const KryGeo &g, int dir, int idx, bool to_buf, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,

@@ -380,8 +380,9 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int col = c0 + 2 * lane;              // column of .x ; grid index i = col - 2
 	const int ix = col - 2;
 	// strict interior: the points that count in the dot products here
-	const bool mxx = (ix >= 1 && ix <= g.mx - 1);
-	const bool mxy = (ix + 1 >= 1 && ix + 1 <= g.mx - 1);
+	const int ix_first = (GEN && g.nb[0]) ? 0 : 1;     // an x interface counts on its upper side
+	const bool mxx = (ix >= ix_first && ix <= g.mx - 1);
+	const bool mxy = (ix + 1 >= ix_first && ix + 1 <= g.mx - 1);
 	// cells whose vector updates are stored / points whose operator value is stored
 	const bool uxx = GEN ? (ix >= -1 && ix <= g.mx + 1) : mxx;
 	const bool uxy = GEN ? (ix + 1 >= -1 && ix + 1 <= g.mx + 1) : mxy;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		const int j = y0 + r;
 		off[e] = (long)(j + 1) * g.px + col;
 		lidx[e] = (r + 1) * LW + 2 + 2 * lane;
-		mrow[e] = (j >= 1 && j <= g.my - 1);
+		mrow[e] = (j >= 1 && (j <= g.my - 1 || (GEN && j == g.my && g.nb[3])));   // a y interface counts on its lower side
 		urow[e] = GEN ? (j <= g.my + 1) : mrow[e];
 		orow[e] = GEN ? (j >= 0 && j <= g.my) : mrow[e];
 	}
@@ -651,12 +652,22 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 	double acc[ND];
 #pragma unroll
 	for (int k = 0; k < ND; ++k) acc[k] = 0.;
-	// item counts fit 32 bits for any grid the allocation limits allow (checked by the host)
-	const unsigned nx1 = g.mx + 1, ny1 = g.my + 1, nym = g.my - 1;
-	const unsigned nxy = nx1 * ny1;
+	// Counted points per direction (interfaces count once, see KryGeo::nb) and the
+	// faces of the global domain among this sub-domain's faces.  Item counts fit 32 bits.
+	const int cx0 = 0, cx1 = g.nb[1] ? g.mx - 1 : g.mx;
+	const int cy0 = g.nb[2] ? 1 : 0;
+	const unsigned nx1 = cx1 - cx0 + 1;
+	// the z-face family walks ALL points of the face (each holder of an interface row
+	// applies the z-face treatment to its own copy) and gives the uncounted ones weight 0
+	const unsigned nxa = g.mx + 1, nya = g.my + 1;
+	const unsigned nxy = nxa * nya;
 	const unsigned nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
+	const unsigned nyf = (g.nb[2] ? 0 : 1) + (g.nb[3] ? 0 : 1);
+	const unsigned nxf = (g.nb[0] ? 0 : 1) + (g.nb[1] ? 0 : 1);
 	const int k1 = 1, k2 = g.has_hi ? g.mz : g.mz - 1, nk = k2 - k1 + 1;
-	const unsigned tz = nzf * nxy, ty = 2u * nk * nx1, tx = 2u * nk * nym;
+	const int j1 = 1, j2 = g.nb[3] ? g.my : g.my - 1;
+	const unsigned nym = j2 - j1 + 1;
+	const unsigned tz = nzf * nxy, ty = nyf * nk * nx1, tx = nxf * nk * nym;
 	const unsigned total = tz + ty + tx;
 	for (unsigned t = blockIdx.x * NT + threadIdx.x; t < total; t += gridDim.x * NT) {
 		int i, j, k;
@@ -664,25 +675,30 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 		if (t < tz) {
 			const unsigned f = t / nxy;
 			const unsigned rem = t - f * nxy;
-			j = (int)(rem / nx1);
-			i = (int)(rem - (unsigned)j * nx1);
+			j = (int)(rem / nxa);
+			i = (int)(rem - (unsigned)j * nxa);
 			k = (f == 0 && !g.has_lo) ? 0 : g.mz;
 			bz = true;
 		} else if (t < tz + ty) {
 			const unsigned rem = t - tz;
 			const unsigned r2 = rem / nx1;
-			i = (int)(rem - r2 * nx1);
-			j = (r2 & 1) ? g.my : 0;
-			k = k1 + (int)(r2 >> 1);
+			i = cx0 + (int)(rem - r2 * nx1);
+			const unsigned side = r2 % nyf;
+			j = (side == 0 && !g.nb[2]) ? 0 : g.my;
+			k = k1 + (int)(r2 / nyf);
 		} else {
 			const unsigned rem = t - tz - ty;
 			const unsigned r2 = rem / nym;
-			j = 1 + (int)(rem - r2 * nym);
-			i = (r2 & 1) ? g.mx : 0;
-			k = k1 + (int)(r2 >> 1);
+			j = j1 + (int)(rem - r2 * nym);
+			const unsigned side = r2 % nxf;
+			i = (side == 0 && !g.nb[0]) ? 0 : g.mx;
+			k = k1 + (int)(r2 / nxf);
 		}
-		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
-		const double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
+		// weight 1/2 per face of the global domain the point lies on
+		const bool bx = (i == 0 && !g.nb[0]) || (i == g.mx && !g.nb[1]);
+		const bool by = (j == 0 && !g.nb[2]) || (j == g.my && !g.nb[3]);
+		const bool counted = (i <= cx1 && j >= cy0);
+		const double wgt = counted ? (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.) : 0.;
 		const long p = kry_idx(g, i, j, k);
 		double o;
 		if (bz) {
@@ -743,8 +759,10 @@ __device__ inline void plane_weights(const KryGeo &g, long q, double (&wxy)[2], 
 		const long qq = q + d + QOFF;
 		const int row = (int)(qq / g.px);
 		const int i = (int)(qq - (long)row * g.px) - 2, j = row - 1;
-		const bool in = (i >= 0 && i <= g.mx && j >= 0 && j <= g.my);
-		const bool bx = (i == 0 || i == g.mx), by = (j == 0 || j == g.my);
+		// counted points: interfaces once (KryGeo::nb); 1/2 per face of the global domain
+		const bool in = (i >= 0 && i <= (g.nb[1] ? g.mx - 1 : g.mx) && j >= (g.nb[2] ? 1 : 0) && j <= g.my);
+		const bool bx = (i == 0 && !g.nb[0]) || (i == g.mx && !g.nb[1]);
+		const bool by = (j == 0 && !g.nb[2]) || (j == g.my && !g.nb[3]);
 		wxy[d] = in ? (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) : 0.;
 		corner[d] = in && bx && by;
 	}
@@ -919,6 +937,21 @@ __global__ __launch_bounds__(NT) void g_repack(double *dev, double *packed, int 
 	}
 }
 
+// One x plane (dir 0: i = idx, all j, k of the stored box) or one y row set (dir 1:
+// j = idx, all i, k) between a field and a packed buffer, for the halo exchange with
+// x and y neighbours (BoundaryHandler.C:579-1045 packs the same full tangential box).
+// dir 0: buf[(k+1)*(my+3) + (j+1)];  dir 1: buf[(k+1)*(mx+3) + (i+1)].
+__global__ __launch_bounds__(NT) void g_face(double *field, double *buf, KryGeo g, int dir, int idx, int to_buf)
+{
+	const long na = (dir == 0 ? g.my : g.mx) + 3, nb = g.mz + 3;
+	for (long t = (long)blockIdx.x * NT + threadIdx.x; t < na * nb; t += (long)gridDim.x * NT) {
+		const int a = (int)(t % na) - 1, k = (int)(t / na) - 1;
+		const long p = dir == 0 ? kry_idx(g, idx, a, k) : kry_idx(g, a, idx, k);
+		if (to_buf) buf[t] = field[p];
+		else field[p] = buf[t];
+	}
+}
+
 // dst = a - b (Krylov.C:259)
 __global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const double *y, long n2)
 {
@@ -942,26 +975,34 @@ __global__ void g_bc(double *d, KryGeo g, int dir)
 		const int j = a - 1, k = b - 1;
 		if (j > g.my + 1) return;
 		double *row = d + kry_idx(g, 0, j, k);   // row[i] = value at grid index i
-		if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
-		else if (g.bc[0] == 1) row[-1] = 2. * row[0] - row[1];
+		if (!g.nb[0]) {
+			if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
+			else if (g.bc[0] == 1) row[-1] = 2. * row[0] - row[1];
+		}
 		const int m = g.mx;
-		if (g.bc[1] == 0) { row[m] = 0.; row[m + 1] = 0.; }
-		else if (g.bc[1] == 1) {
-			row[m] = 2. * row[m - 1] - row[m - 2];
-			row[m + 1] = 2. * row[m] - row[m - 1];
+		if (!g.nb[1]) {
+			if (g.bc[1] == 0) { row[m] = 0.; row[m + 1] = 0.; }
+			else if (g.bc[1] == 1) {
+				row[m] = 2. * row[m - 1] - row[m - 2];
+				row[m + 1] = 2. * row[m] - row[m - 1];
+			}
 		}
 	} else if (dir == 1) {
 		const int i = a, k = b - 1;
 		if (i > g.mx) return;
 		double *c = d + kry_idx(g, i, 0, k);     // c[j*px]
 		const long s = g.px;
-		if (g.bc[2] == 0) { c[-s] = 0.; c[0] = 0.; }
-		else if (g.bc[2] == 1) c[-s] = 2. * c[0] - c[s];
+		if (!g.nb[2]) {
+			if (g.bc[2] == 0) { c[-s] = 0.; c[0] = 0.; }
+			else if (g.bc[2] == 1) c[-s] = 2. * c[0] - c[s];
+		}
 		const int m = g.my;
-		if (g.bc[3] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
-		else if (g.bc[3] == 1) {
-			c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
-			c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
+		if (!g.nb[3]) {
+			if (g.bc[3] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
+			else if (g.bc[3] == 1) {
+				c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
+				c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
+			}
 		}
 	} else {
 		const int i = a, j = b;
@@ -1036,12 +1077,13 @@ __global__ __launch_bounds__(NT) void g_wdot(KryGeo g, const double *x, const do
 	double acc[1] = {0.};
 	for (long row = (long)blockIdx.x * NW + w; row < rows; row += (long)gridDim.x * NW) {
 		const int j = (int)(row % (g.my + 1)), k = (int)(row / (g.my + 1));
-		const bool by = (j == 0 || j == g.my);
+		const bool by = (j == 0 && !g.nb[2]) || (j == g.my && !g.nb[3]);
 		const bool bz = (k == 0 && !g.has_lo) || (k == g.mz && !g.has_hi);
-		if (k == 0 && g.has_lo) continue;
+		if ((k == 0 && g.has_lo) || (j == 0 && g.nb[2])) continue;   // counted by the lower neighbour
 		const long p0 = kry_idx(g, 0, j, k);
-		for (int i = lane; i <= g.mx; i += 64) {
-			const bool bx = (i == 0 || i == g.mx);
+		const int ilast = g.nb[1] ? g.mx - 1 : g.mx;                 // an x interface counts on its upper side
+		for (int i = lane; i <= ilast; i += 64) {
+			const bool bx = (i == 0 && !g.nb[0]) || (i == g.mx && !g.nb[1]);
 			double wgt = (bx ? 0.5 : 1.) * (by ? 0.5 : 1.) * (bz ? 0.5 : 1.);
 			if (norm_mode && bx && by && bz) wgt = 0.25;
 			acc[0] += wgt * (x[p0 + i] * y[p0 + i]);
@@ -1067,26 +1109,28 @@ static hipError_t launch_fused_t(const KryFused &a, bool var, bool offd, bool ex
 	return hipGetLastError();
 }
 
-// general-boundary variants: field coefficients only, 8-row tiles
+// general-boundary variants, 8-row tiles (constant coefficients: only where no face
+// of the global domain needs the operator's input treated, i.e. all of them Dirichlet)
 template <int KIND>
-static hipError_t launch_fused_gen_t(const KryFused &a, bool offd, bool exact, hipStream_t st)
+static hipError_t launch_fused_gen_t(const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
 {
 	dim3 grid(a.nblk), block(NT);
-#define KRY_LAUNCH(O, E) hipLaunchKernelGGL((k_fused<KIND, 8, true, O, E, true>), grid, block, 0, st, a)
-	if (!offd) { if (exact) KRY_LAUNCH(false, true); else KRY_LAUNCH(false, false); }
-	else { if (exact) KRY_LAUNCH(true, true); else KRY_LAUNCH(true, false); }
+#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, 8, V, O, E, true>), grid, block, 0, st, a)
+	if (!var) KRY_LAUNCH(false, false, true);
+	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
+	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
 #undef KRY_LAUNCH
 	return hipGetLastError();
 }
 
-hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool offd, bool exact, hipStream_t st)
+hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
 {
 	switch (kind) {
-	case KF_A0:  return launch_fused_gen_t<KF_A0>(a, offd, exact, st);
-	case KF_A1:  return launch_fused_gen_t<KF_A1>(a, offd, exact, st);
-	case KF_B0:  return launch_fused_gen_t<KF_B0>(a, offd, exact, st);
-	case KF_B0L: return launch_fused_gen_t<KF_B0L>(a, offd, exact, st);
-	case KF_B1L: return launch_fused_gen_t<KF_B1L>(a, offd, exact, st);
+	case KF_A0:  return launch_fused_gen_t<KF_A0>(a, var, offd, exact, st);
+	case KF_A1:  return launch_fused_gen_t<KF_A1>(a, var, offd, exact, st);
+	case KF_B0:  return launch_fused_gen_t<KF_B0>(a, var, offd, exact, st);
+	case KF_B0L: return launch_fused_gen_t<KF_B0L>(a, var, offd, exact, st);
+	case KF_B1L: return launch_fused_gen_t<KF_B1L>(a, var, offd, exact, st);
 	}
 	return hipErrorInvalidValue;
 }
@@ -1164,6 +1208,14 @@ hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int 
 {
 	hipLaunchKernelGGL(g_repack, dim3((unsigned)std::min<long>((rows + NW - 1) / NW, 32768)), dim3(NT), 0, st, dev, packed, w,
 	                   rows, px, to_device ? 1 : 0);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_face(double *field, double *buf, const KryGeo &g, int dir, int idx, bool to_buf, hipStream_t st)
+{
+	const long n = (long)((dir == 0 ? g.my : g.mx) + 3) * (g.mz + 3);
+	hipLaunchKernelGGL(g_face, dim3((unsigned)std::min<long>((n + NT - 1) / NT, 4096)), dim3(NT), 0, st, field, buf, g, dir, idx,
+	                   to_buf ? 1 : 0);
 	return hipGetLastError();
 }
 

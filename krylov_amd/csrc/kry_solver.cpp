@@ -82,6 +82,8 @@ struct Slab {
 	double *gather = nullptr;  // slab_count * KRY_NSUMS doubles (used on the first slab)
 	double *stage = nullptr;   // device staging buffer of the host<->device copies (freed after use)
 	size_t stage_cap = 0;
+	double *xy_buf = nullptr;  // packed x / y faces of the Cartesian split: 3 planes out, 3 planes in
+	size_t xy_plane = 0;       // doubles per packed plane slot
 	std::vector<Field *> all;
 };
 
@@ -99,6 +101,13 @@ struct kry_solver {
 	int mzl = 0;               // slab-local mz
 	bool fused = false;        // fused path in use (device-resident recurrences)
 	bool gen = false;          // its general-boundary variant (any face types, field coefficients)
+	// Cartesian split of the global domain over processes (mpi_manager.C:56-305): np
+	// sub-domains per direction, this process at co.  {1,1,nslabs} for plain z slabs.
+	int np[3] = {1, 1, 1}, co[3] = {0, 0, 0};
+	bool cart = false;         // split in x or y as well (one sub-domain per process)
+	int rank_of(int cx, int cy, int cz) const { return (cx * np[1] + cy) * np[2] + cz; }   // reorder = 0
+	int my_rank() const { return rank_of(co[0], co[1], co[2]); }
+	int n_ranks() const { return np[0] * np[1] * np[2]; }
 	bool var = false, offd = false;
 	bool loaded = false;
 	KryOp op;
@@ -304,10 +313,54 @@ int reduce_sums(kry_solver *h, int phase)
 // Fill the neighbour-owned ghost planes of a stencil output: plane 1 goes to the
 // lower neighbour's ghost mz+1, plane mz-1 to the upper neighbour's ghost -1
 // (BoundaryHandler.C:615-618, 761-765 for direction 2).
+// x and y neighbours of a Cartesian split (one sub-domain per process).  Per
+// direction: planes 1 and m-1 fill the neighbours' ghosts m+1 and -1 over the full
+// tangential box, ghost layers included, so edges and corners arrive in two or three
+// hops as in BoundaryHandler.C:579-1045.  In x the interface plane travels too (0 ->
+// the lower neighbour's mx): the fused kernels evaluate the operator on the upper
+// side of an x interface only.
+int exchange_xy(kry_solver *h, double *f)
+{
+	Slab &s = h->slabs[0];
+	const KryGeo &g = s.g;
+	HIPCHK(hipSetDevice(s.device));
+	for (int dir = 0; dir < 2; ++dir) {
+		if (!g.nb[2 * dir] && !g.nb[2 * dir + 1]) continue;
+		const int m = dir == 0 ? g.mx : g.my;
+		const size_t n = (size_t)((dir == 0 ? g.my : g.mx) + 3) * (g.mz + 3);
+		// slots of xy_buf: [send_lo x2 | send_hi x2 | recv_lo x2 | recv_hi x2]; x uses two planes
+		// per message in both directions (the second one of the upward message is padding)
+		const size_t slot = s.xy_plane;
+		double *send_lo = s.xy_buf, *send_hi = s.xy_buf + 2 * slot;
+		double *recv_lo = s.xy_buf + 4 * slot, *recv_hi = s.xy_buf + 6 * slot;
+		const int nl = dir == 0 ? 2 : 1;
+		int cc[3] = {h->co[0], h->co[1], h->co[2]};
+		int peer_lo = -1, peer_hi = -1;
+		if (g.nb[2 * dir]) { cc[dir] -= 1; peer_lo = h->rank_of(cc[0], cc[1], cc[2]); cc[dir] += 1; }
+		if (g.nb[2 * dir + 1]) { cc[dir] += 1; peer_hi = h->rank_of(cc[0], cc[1], cc[2]); cc[dir] -= 1; }
+		if (peer_lo >= 0) {
+			HIPCHK(kry_launch_face(f, send_lo, g, dir, 1, true, s.st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, send_lo + n, g, dir, 0, true, s.st));
+		}
+		if (peer_hi >= 0) {
+			HIPCHK(kry_launch_face(f, send_hi, g, dir, m - 1, true, s.st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, send_hi + n, g, dir, m - 2, true, s.st));
+		}
+		CHK(h->comm.halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (size_t)nl * n, s.st));
+		if (peer_hi >= 0) {
+			HIPCHK(kry_launch_face(f, recv_hi, g, dir, m + 1, false, s.st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, recv_hi + n, g, dir, m, false, s.st));
+		}
+		if (peer_lo >= 0) HIPCHK(kry_launch_face(f, recv_lo, g, dir, -1, false, s.st));
+	}
+	return 0;
+}
+
 int exchange_halo(kry_solver *h, std::vector<double *> &f)
 {
 	const int ns = (int)h->slabs.size();
 	if (ns == 1 && !h->comm.active()) return 0;
+	if (h->cart) CHK(exchange_xy(h, f[0]));
 	const size_t bytes = (size_t)h->slabs[0].g.ps * sizeof(double);
 	for (int i = 0; i < ns; ++i) {
 		HIPCHK(hipSetDevice(h->slabs[i].device));
@@ -332,9 +385,9 @@ int exchange_halo(kry_solver *h, std::vector<double *> &f)
 		const KryGeo &g = s.g;
 		double *b = f[0];
 		HIPCHK(hipSetDevice(s.device));
-		CHK(h->comm.halo(g.has_lo ? s.index - 1 : -1, b + 2L * g.ps, b,
-		                 g.has_hi ? s.index + 1 : -1, b + (long)g.mz * g.ps, b + (long)(g.mz + 2) * g.ps,
-		                 (size_t)g.ps, s.st));
+		CHK(h->comm.halo(g.has_lo ? h->rank_of(h->co[0], h->co[1], h->co[2] - 1) : -1, b + 2L * g.ps, b,
+		                 g.has_hi ? h->rank_of(h->co[0], h->co[1], h->co[2] + 1) : -1, b + (long)g.mz * g.ps,
+		                 b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st));
 	}
 	return 0;
 }
@@ -368,8 +421,9 @@ int exchange_halo_begin(kry_solver *h, std::vector<double *> &f)
 		}
 		if (h->comm.active()) {
 			double *b = f[i];
-			CHK(h->comm.halo(g.has_lo ? s.index - 1 : -1, b + 2L * g.ps, b, g.has_hi ? s.index + 1 : -1,
-			                 b + (long)g.mz * g.ps, b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st_comm));
+			CHK(h->comm.halo(g.has_lo ? h->rank_of(h->co[0], h->co[1], h->co[2] - 1) : -1, b + 2L * g.ps, b,
+			                 g.has_hi ? h->rank_of(h->co[0], h->co[1], h->co[2] + 1) : -1, b + (long)g.mz * g.ps,
+			                 b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st_comm));
 		}
 		HIPCHK(hipEventRecord(s.ev_halo, s.st_comm));
 	}
@@ -454,7 +508,7 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 {
 	HIPCHK(hipSetDevice(s.device));
 	if (prof & 1) prof_begin(h, s, kind);
-	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->offd, h->op.exact_rcp != 0, s.st));
+	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 	else HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 	if (prof & 2) prof_end(h, s);
 	return 0;
@@ -463,10 +517,13 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 // blocks of the boundary-plane dot kernel that follows a general-boundary stencil kernel
 int surf_blocks(const KryGeo &g)
 {
-	const long nxy = (long)(g.mx + 1) * (g.my + 1);
+	// the item count of k_surf
+	const long nx1 = (g.nb[1] ? g.mx - 1 : g.mx) + 1;
 	const int nzf = (g.has_lo ? 0 : 1) + (g.has_hi ? 0 : 1);
+	const int nyf = (g.nb[2] ? 0 : 1) + (g.nb[3] ? 0 : 1), nxf = (g.nb[0] ? 0 : 1) + (g.nb[1] ? 0 : 1);
 	const int nk = (g.has_hi ? g.mz : g.mz - 1);
-	const long total = nzf * nxy + 2L * nk * (g.mx + 1) + 2L * nk * (g.my - 1);
+	const long nym = (g.nb[3] ? g.my : g.my - 1);
+	const long total = (long)nzf * (g.mx + 1) * (g.my + 1) + (long)nyf * nk * nx1 + (long)nxf * nk * nym;
 	return (int)std::max<long>(1, std::min<long>((total + 255) / 256, KRY_SURF_BLOCKS));
 }
 
@@ -1118,11 +1175,13 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	// face types: their general-boundary variant, for field coefficients only (the
 	// constant-coefficient operator re-applies the boundary treatment to its INPUT,
 	// Krylov.C:516, which cannot be folded into the producing update).
+	// A split in x or y runs the general-boundary variant too: its ghost-cell handling
+	// is what neighbours in those directions need.
 	const bool can_fuse = h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
 	bool extrapolating = true;     // every face of type 0 or 1
 	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
-	h->gen = can_fuse && !dirichlet && extrapolating && var;
-	h->fused = can_fuse && (dirichlet || h->gen);
+	h->gen = can_fuse && extrapolating && ((!dirichlet && var) || (h->cart && (var || dirichlet)));
+	h->fused = can_fuse && ((dirichlet && !h->cart) || h->gen);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
 	if (h->slabs.size() > 1 || h->comm.active()) {
 		// interface ghosts of the inputs, as solve_int does under `parallel`
@@ -1202,6 +1261,15 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	}
 	for (int k = 0; k < 3; ++k)
 		if (d->mx[k] < 4 || !(d->delx[k] > 0.)) { set_err("bad grid: mx[%d]=%d delx=%g", k, d->mx[k], d->delx[k]); return fail(KRY_ERR_ARG); }
+	const bool has_cart = d->nproc[0] > 0 || d->nproc[1] > 0 || d->nproc[2] > 0;
+	if (has_cart) {
+		for (int k = 0; k < 3; ++k)
+			if (d->nproc[k] < 1 || d->coord[k] < 0 || d->coord[k] >= d->nproc[k]) {
+				set_err("bad Cartesian split: nproc[%d]=%d coord=%d", k, d->nproc[k], d->coord[k]);
+				return fail(KRY_ERR_ARG);
+			}
+		if (d->slab_count != 1) { set_err("a Cartesian split takes one sub-domain per process (slab_count=%d)", d->slab_count); return fail(KRY_ERR_ARG); }
+	}
 	if (d->mx[2] % d->slab_count != 0 || d->mx[2] / d->slab_count < 4) {
 		set_err("mz=%d not divisible into %d slabs of >= 4 planes", d->mx[2], d->slab_count);
 		return fail(KRY_ERR_ARG);
@@ -1218,6 +1286,15 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	h->d = *d;
 	h->L = d->L;
 	h->mzl = d->mx[2] / d->slab_count;
+	if (has_cart) {
+		for (int k = 0; k < 3; ++k) { h->np[k] = d->nproc[k]; h->co[k] = d->coord[k]; }
+		h->cart = h->np[0] > 1 || h->np[1] > 1;
+		h->d.nslabs = h->np[2];
+		h->d.slab_begin = h->co[2];
+	} else {
+		h->np[2] = d->nslabs;
+		h->co[2] = d->slab_begin;
+	}
 	if (const char *e = getenv("KRY_TY")) h->ty = (atoi(e) == 8) ? 8 : 16;
 	if (const char *e = getenv("KRY_ZC")) { h->zc = std::max(1, atoi(e)); h->zc_fixed = true; }
 	if (const char *e = getenv("KRY_STREAM_BLOCKS")) h->stream_blocks = std::max(64, atoi(e));
@@ -1228,7 +1305,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	auto build = [&]() -> int {
 		for (int i = 0; i < d->slab_count; ++i) {
 			Slab &s = h->slabs[i];
-			s.index = d->slab_begin + i;
+			s.index = h->d.slab_begin + i;
 			s.device = d->devices[i];
 			HIPCHK(hipSetDevice(s.device));
 			HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
@@ -1243,7 +1320,9 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			g.ps = (long)g.px * (g.my + 3);
 			g.n = g.ps * (g.mz + 3);
 			g.has_lo = s.index > 0;
-			g.has_hi = s.index < d->nslabs - 1;
+			g.has_hi = s.index < h->d.nslabs - 1;
+			for (int k = 0; k < 2; ++k) { g.nb[2 * k] = h->co[k] > 0; g.nb[2 * k + 1] = h->co[k] < h->np[k] - 1; }
+			g.nb[4] = g.has_lo; g.nb[5] = g.has_hi;
 			for (int f = 0; f < 6; ++f) g.bc[f] = d->bc_type[f];
 			s.guard = 20L * g.px + 256;
 			CHK(alloc_field(s, s.phi));
@@ -1274,6 +1353,10 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			HIPCHK(hipMalloc((void **)&s.counter, 64));
 			HIPCHK(hipMemsetAsync(s.counter, 0, 64, s.st));
 			HIPCHK(hipMalloc((void **)&s.gather, sizeof(double) * KRY_NSUMS * (KRY_MAX_SLABS + 1)));
+			if (h->cart) {
+				s.xy_plane = (size_t)(std::max(g.mx, g.my) + 3) * (g.mz + 3);
+				HIPCHK(hipMalloc((void **)&s.xy_buf, 8 * s.xy_plane * sizeof(double)));
+			}
 			HIPCHK(hipStreamSynchronize(s.st));
 		}
 		// peer access between the devices of neighbouring local slabs
@@ -1317,6 +1400,7 @@ void kry_destroy(kry_handle h)
 		if (s.counter) hipFree(s.counter);
 		if (s.gather) hipFree(s.gather);
 		if (s.stage) hipFree(s.stage);
+		if (s.xy_buf) hipFree(s.xy_buf);
 		if (s.ev) hipEventDestroy(s.ev);
 		if (s.ev_in) hipEventDestroy(s.ev_in);
 		if (s.ev_edge) hipEventDestroy(s.ev_edge);
@@ -1338,9 +1422,9 @@ int kry_comm_unique_id(void *uid)
 int kry_comm_init(kry_handle h, const void *uid, int rank, int nranks)
 {
 	if (!h || !uid) { set_err("null argument"); return KRY_ERR_ARG; }
-	if (h->d.slab_count != 1 || h->d.nslabs != nranks || h->d.slab_begin != rank) {
-		set_err("kry_comm_init: rank r must own exactly slab r (nslabs=%d begin=%d count=%d, rank=%d/%d)",
-		        h->d.nslabs, h->d.slab_begin, h->d.slab_count, rank, nranks);
+	if (h->d.slab_count != 1 || h->n_ranks() != nranks || h->my_rank() != rank) {
+		set_err("kry_comm_init: rank r must own exactly sub-domain r (split %dx%dx%d, this one is number %d; rank=%d/%d)",
+		        h->np[0], h->np[1], h->np[2], h->my_rank(), rank, nranks);
 		return KRY_ERR_ARG;
 	}
 	hipSetDevice(h->slabs[0].device);
@@ -1375,9 +1459,9 @@ int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb
                             void *ctx)
 {
 	if (!h) { set_err("null argument"); return KRY_ERR_ARG; }
-	if (h->d.slab_count != 1 || h->d.nslabs != nranks || h->d.slab_begin != rank) {
-		set_err("kry_comm_init_callbacks: rank r must own exactly slab r (nslabs=%d begin=%d count=%d, rank=%d/%d)",
-		        h->d.nslabs, h->d.slab_begin, h->d.slab_count, rank, nranks);
+	if (h->d.slab_count != 1 || h->n_ranks() != nranks || h->my_rank() != rank) {
+		set_err("kry_comm_init_callbacks: rank r must own exactly sub-domain r (split %dx%dx%d, this one is number %d; rank=%d/%d)",
+		        h->np[0], h->np[1], h->np[2], h->my_rank(), rank, nranks);
 		return KRY_ERR_ARG;
 	}
 	int st = h->comm.init_callbacks(rank, nranks, allreduce, halo, ctx);
@@ -1389,9 +1473,9 @@ int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allredu
                                  void *ctx)
 {
 	if (!h) { set_err("null argument"); return KRY_ERR_ARG; }
-	if (h->d.slab_count != 1 || h->d.nslabs != nranks || h->d.slab_begin != rank) {
-		set_err("kry_comm_init_host_callbacks: rank r must own exactly slab r (nslabs=%d begin=%d count=%d, rank=%d/%d)",
-		        h->d.nslabs, h->d.slab_begin, h->d.slab_count, rank, nranks);
+	if (h->d.slab_count != 1 || h->n_ranks() != nranks || h->my_rank() != rank) {
+		set_err("kry_comm_init_host_callbacks: rank r must own exactly sub-domain r (split %dx%dx%d, this one is number %d; rank=%d/%d)",
+		        h->np[0], h->np[1], h->np[2], h->my_rank(), rank, nranks);
 		return KRY_ERR_ARG;
 	}
 	hipSetDevice(h->slabs[0].device);
@@ -1483,7 +1567,8 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	if (h->L == 1) W = h->var ? (h->offd ? 28 : 26) : 20;
 	else if (h->L == 2) W = h->var ? (h->offd ? 66 : 62) : 50;
 	else W = 0;
-	const double npts = (double)(h->d.mx[0] + 1) * (h->d.mx[1] + 1) * ((double)h->mzl * h->d.nslabs + 1);
+	const double npts = ((double)h->d.mx[0] * h->np[0] + 1) * ((double)h->d.mx[1] * h->np[1] + 1) *
+	                    ((double)h->mzl * h->d.nslabs + 1);
 	o->bytes_per_iter = 8.0 * W * npts;
 	for (int k = 0; k < 8; ++k) { o->kernel_ms[k] = h->kernel_ms[k]; o->kernel_calls[k] = h->kernel_calls[k]; }
 	o->tile_rows = h->gen ? 8 : h->ty;

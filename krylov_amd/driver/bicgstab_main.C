@@ -9,9 +9,10 @@
 //   bicgstab [-n MX] [-t 1..5] [-r] [-l L] [-e TOL] [-i MAXITER] [--stats] [-q]
 //
 // Built with -D parallel (and an MPI installation) it is the reference's parallel
-// driver: `mpiexec -n P bicgstab_mpi ...` splits the domain into P z slabs
-// (nproc = {1, 1, P}; the reference hard-codes {2, 2, 2}, BICGStab3D/main.C:145-150),
-// one process and one GPU each (KRY_DEVICES lists the devices, default all on 0).
+// driver: `mpiexec -n P bicgstab_mpi ...` splits the domain over P processes, one GPU
+// each (KRY_DEVICES lists the devices, default all on 0): 2 x 2 x 2 for P = 8 as the
+// reference hard-codes (BICGStab3D/main.C:145-150), P z slabs otherwise, or
+// `--nproc NX NY NZ`.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -48,6 +49,7 @@ struct Options {
 	bool stats = false;
 	bool quiet = false;
 	unsigned seed = 12345;
+	int nproc[3] = {0, 0, 0};   // -D parallel: process grid (0 = choose from the process count)
 };
 
 void usage(const char *argv0)
@@ -86,6 +88,7 @@ bool parse(int argc, char **argv, Options &o)
 		else if (a == "-e" || a == "--tolerance") o.tol = atof(need("Tolerance"));
 		else if (a == "-i" || a == "--iterations") o.max_iter = atoi(need("Iterations"));
 		else if (a == "-s" || a == "--seed") o.seed = (unsigned)atol(need("Seed"));
+		else if (a == "--nproc") { for (int d = 0; d < 3; ++d) o.nproc[d] = atoi(need("Process grid")); }
 		else if (a == "--stats") o.stats = true;
 		else if (a == "-q" || a == "--quiet") o.quiet = true;
 		else if (!a.empty() && a[0] != '-') o.mx = atoi(a.c_str());
@@ -118,9 +121,11 @@ int main(int argc, char *argv[])
 	for (int b = 0; b < 6; ++b) MyGrid.set_bcType(b, 0);
 
 #ifdef parallel
-	// BICGStab3D/main.C:145-186, with the split along z
+	// BICGStab3D/main.C:145-186
 	NumArray<int> nproc(3), mx_global(3);
-	nproc[0] = 1; nproc[1] = 1; nproc[2] = ntasks;
+	if (opt.nproc[0] > 0) { nproc[0] = opt.nproc[0]; nproc[1] = opt.nproc[1]; nproc[2] = opt.nproc[2]; }
+	else if (ntasks == 8) { nproc[0] = nproc[1] = nproc[2] = 2; }
+	else { nproc[0] = 1; nproc[1] = 1; nproc[2] = ntasks; }
 	mx_global[0] = mx_global[1] = mx_global[2] = opt.mx;
 	mpi_manager_3D MyMPI(nproc, mx_global);
 	grid_manager LocalGrid = MyMPI.make_LocalGrid(MyGrid);

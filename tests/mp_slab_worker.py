@@ -4,7 +4,8 @@ the C ABI, implemented with device<->host copies and torch.distributed (gloo);
 everything else is the library's own multi-process code path (the same one the
 RCCL transport drives on a multi-GPU node).
 
-usage: mp_slab_worker.py RANK WORLD PORT KIND L MAX_OUTER EPS OUTDIR
+usage: mp_slab_worker.py RANK WORLD PORT KIND L MAX_OUTER EPS OUTDIR [NX,NY,NZ]
+(with a split NX,NY,NZ the processes form a Cartesian grid, rank = (cx*NY + cy)*NZ + cz)
 """
 import os
 import sys
@@ -20,6 +21,7 @@ sys.path.insert(0, HERE)
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     kind, L, max_outer, eps, outdir = sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7]), sys.argv[8]
+    nproc = tuple(int(v) for v in sys.argv[9].split(",")) if len(sys.argv) > 9 else None
 
     # the solver library (and with it the ROCm HIP runtime) before torch
     from krylov_amd import capi, problems as P
@@ -34,10 +36,17 @@ def main():
     import slab_reference as SR
     from test_gpu_multiproc import make_problem
     p = make_problem(kind)
-    loc = SR.split_problem(P, p, world, rank)
-    flags = capi.KRY_FORCE_GENERIC if kind == "mixed_generic" else 0
-    with capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs=world,
-                     slab_begin=rank, slab_count=1, devices=(0,)) as s:
+    flags = capi.KRY_FORCE_GENERIC if kind.endswith("_generic") else 0
+    if nproc is None:
+        loc = SR.split_problem(P, p, world, rank)
+        solver = capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs=world,
+                             slab_begin=rank, slab_count=1, devices=(0,))
+    else:
+        coord = (rank // (nproc[1] * nproc[2]), (rank // nproc[2]) % nproc[1], rank % nproc[2])
+        loc = SR.split_brick(P, p, nproc, coord)
+        solver = capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, devices=(0,),
+                             nproc=nproc, coord=coord)
+    with solver as s:
         s.comm_init_callbacks(rank, world, allreduce, halo)
         phi = loc.phi.copy()
         if loc.var_coef:

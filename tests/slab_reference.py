@@ -133,3 +133,15 @@ def split_problem(P, p, nranks, rank):
     cut = lambda a: None if a is None else np.ascontiguousarray(a[sl])
     return P.Problem(p.name, (p.mx[0], p.mx[1], mzl), p.delx, p.bc, p.var_coef, p.use_offdiag, p.Dc,
                      cut(p.phi), cut(p.rhs), cut(p.lam), cut(p.Dxx), cut(p.Dyy), cut(p.Dzz), cut(p.Dxy))
+
+
+def split_brick(P, p, nproc, coord):
+    """Sub-domain `coord` of an nproc[0] x nproc[1] x nproc[2] Cartesian split of a
+    global Problem, ghost layers taken from the global fields (arrays are z, y, x)."""
+    m = [p.mx[d] // nproc[d] for d in range(3)]
+    sx = slice(coord[0] * m[0], coord[0] * m[0] + m[0] + 3)
+    sy = slice(coord[1] * m[1], coord[1] * m[1] + m[1] + 3)
+    sz = slice(coord[2] * m[2], coord[2] * m[2] + m[2] + 3)
+    cut = lambda a: None if a is None else np.ascontiguousarray(a[sz, sy, sx])
+    return P.Problem(p.name, tuple(m), p.delx, p.bc, p.var_coef, p.use_offdiag, p.Dc,
+                     cut(p.phi), cut(p.rhs), cut(p.lam), cut(p.Dxx), cut(p.Dyy), cut(p.Dzz), cut(p.Dxy))

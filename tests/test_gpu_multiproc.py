@@ -19,11 +19,19 @@ gpu = pytest.mark.gpu
 
 def make_problem(kind):
     rng = np.random.default_rng(23)
+    if kind.endswith("_generic") and kind != "mixed_generic":
+        kind = kind[:-len("_generic")]
     if kind == "const":
         p = P.reference_test1(32)
         p.rhs = P.interior_only(rng.uniform(-1, 1, p.rhs.shape))
     elif kind == "var":
         p = P.smooth_var(32)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    elif kind == "offdiag":
+        p = P.offdiag_var(32)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    elif kind in ("mixed32",):
+        p = P.smooth_var(32, bc=(1, 0, 0, 1, 1, 1))
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
     elif kind in ("mixed", "mixed_generic"):
         p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
@@ -41,10 +49,11 @@ def free_port():
     return port
 
 
-def run_ranks(world, kind, L, max_outer, eps, outdir):
+def run_ranks(world, kind, L, max_outer, eps, outdir, nproc=None):
     port = free_port()
+    extra = [",".join(str(v) for v in nproc)] if nproc else []
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_slab_worker.py"), str(r), str(world), str(port),
-                               kind, str(L), str(max_outer), repr(eps), outdir]) for r in range(world)]
+                               kind, str(L), str(max_outer), repr(eps), outdir] + extra) for r in range(world)]
     try:
         codes = [q.wait(timeout=240) for q in procs]
     finally:
@@ -74,6 +83,37 @@ def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
         ref = one["phi"][r * mzl + 1: r * mzl + mzl + 2, 1:-1, 1:-1]
         assert np.max(np.abs(mine - ref)) <= 1e-10 * np.max(np.abs(ref))
     # every rank holds the same history, bit for bit
+    for d in parts[1:]:
+        assert np.array_equal(d["hist"], parts[0]["hist"])
+
+
+@gpu
+@pytest.mark.parametrize("nproc", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)])
+@pytest.mark.parametrize("kind,L", [("const", 2), ("var", 2), ("var", 1), ("offdiag", 2), ("mixed32", 2),
+                                    ("var_generic", 2), ("const_generic", 1)])
+def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, nproc):
+    """Sub-domains in x and y as well (the reference's mpi_manager_3D layout, up to its
+    driver's 2 x 2 x 2): three passes against the undivided solve."""
+    from helpers import points
+    from krylov_amd import capi
+    if kind == "const_generic" and nproc != (2, 2, 2):
+        pytest.skip("covered by the 2 x 2 x 2 case")
+    p = make_problem(kind)
+    flags = capi.KRY_FORCE_GENERIC if kind.endswith("_generic") else 0
+    one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, flags=flags)
+    world = nproc[0] * nproc[1] * nproc[2]
+    parts = run_ranks(world, kind, L, 3, 1e-30, str(tmp_path), nproc)
+    m = [p.mx[d] // nproc[d] for d in range(3)]
+    for r, d in enumerate(parts):
+        c = (r // (nproc[1] * nproc[2]), (r // nproc[2]) % nproc[1], r % nproc[2])
+        assert int(d["iters"]) == 3
+        assert int(d["fused"]) == (0 if flags else 2)
+        assert float(d["norm_rhs"]) == pytest.approx(one["norm_rhs"], rel=1e-13)
+        assert np.max(np.abs(d["hist"] - one["history"])) <= 1e-10 * one["norm_rhs"]
+        mine = d["phi"][1:-1, 1:-1, 1:-1]
+        ref = one["phi"][c[2] * m[2] + 1: c[2] * m[2] + m[2] + 2, c[1] * m[1] + 1: c[1] * m[1] + m[1] + 2,
+                         c[0] * m[0] + 1: c[0] * m[0] + m[0] + 2]
+        assert np.max(np.abs(mine - ref)) <= 1e-10 * np.max(np.abs(ref))
     for d in parts[1:]:
         assert np.array_equal(d["hist"], parts[0]["hist"])
 
