@@ -145,3 +145,56 @@ def split_brick(P, p, nproc, coord):
     cut = lambda a: None if a is None else np.ascontiguousarray(a[sz, sy, sx])
     return P.Problem(p.name, tuple(m), p.delx, p.bc, p.var_coef, p.use_offdiag, p.Dc,
                      cut(p.phi), cut(p.rhs), cut(p.lam), cut(p.Dxx), cut(p.Dyy), cut(p.Dzz), cut(p.Dxy))
+
+
+class BrickSolver(SlabSolver):
+    """The same schedule on a Cartesian split (sub-domains in x, y and z, the layout of
+    the reference's mpi_manager_3D): operator outputs are exchanged x first, then y,
+    then z, each over the full tangential box, so edges and corners travel in two or
+    three hops (BICGStab3D/BoundaryHandler.C:579-1045).  rank = (cx*ny + cy)*nz + cz."""
+
+    def __init__(self, orc, comm, nproc, coord, p_local, L, eps, max_outer):
+        self.orc, self.comm, self.np3, self.co = orc, comm, tuple(nproc), tuple(coord)
+        self.p, self.L, self.eps, self.max_outer = p_local, L, eps, max_outer
+        bc = list(p_local.bc)
+        for d in range(3):
+            if coord[d] > 0:
+                bc[2 * d] = -1
+            if coord[d] < nproc[d] - 1:
+                bc[2 * d + 1] = -1
+        self.cfg = orc.make_cfg(p_local.mx, p_local.delx, bc, var_coef=p_local.var_coef,
+                                use_offdiag=p_local.use_offdiag, Dc=p_local.Dc)
+
+    def _rank(self, c):
+        return (c[0] * self.np3[1] + c[1]) * self.np3[2] + c[2]
+
+    def halo(self, a):
+        for d in range(3):                      # arrays are indexed [z, y, x]
+            ax = 2 - d
+            m = self.p.mx[d]
+            c = list(self.co)
+            lo = hi = None
+            if self.co[d] > 0:
+                c[d] -= 1; lo = self._rank(c); c[d] += 1
+            if self.co[d] < self.np3[d] - 1:
+                c[d] += 1; hi = self._rank(c); c[d] -= 1
+            if lo is None and hi is None:
+                continue
+            take = lambda i: np.ascontiguousarray(np.take(a, i, axis=ax))
+            got_lo, got_hi = self.comm.exchange(lo, take(2), hi, take(m))
+            idx = [slice(None)] * 3
+            if got_lo is not None:
+                idx[ax] = 0; a[tuple(idx)] = got_lo
+            if got_hi is not None:
+                idx[ax] = m + 2; a[tuple(idx)] = got_hi
+
+    def norm(self, a):
+        s = self.orc.dot(self.cfg, a, a)
+        mx, my, mz = self.p.mx
+        on = lambda d, side: self.co[d] == (0 if side == 0 else self.np3[d] - 1)
+        for kz, k in ((0, 1), (1, mz + 1)):
+            for jy, j in ((0, 1), (1, my + 1)):
+                for ix, i in ((0, 1), (1, mx + 1)):
+                    if on(2, kz) and on(1, jy) and on(0, ix):       # a corner of the GLOBAL domain
+                        s += 0.125 * a[k, j, i] * a[k, j, i]
+        return np.sqrt(self.comm.allreduce(s))

@@ -71,6 +71,22 @@ def worker(rank, world, port, kind, L, out_dir):
     dist.destroy_process_group()
 
 
+def brick_worker(rank, world, port, kind, L, nproc, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from krylov_amd import problems as P
+    from oracle import oracle as orc
+    import slab_reference as SR
+    p = make_problem(kind)
+    coord = (rank // (nproc[1] * nproc[2]), (rank // nproc[2]) % nproc[1], rank % nproc[2])
+    local = SR.split_brick(P, p, nproc, coord)
+    phi, hist, nrhs = SR.BrickSolver(orc, GlooComm(rank, world), nproc, coord, local, L, 1e-30, 4).solve()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), phi=phi, hist=np.array(hist), nrhs=nrhs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -101,3 +117,27 @@ def test_slab_schedule_reproduces_the_undivided_solve(orc, tmp_path, kind, L, wo
         if r > 0:
             assert np.max(np.abs(d["phi"][0, 1:-1, 1:-1] - want["phi"][r * mzl, 1:-1, 1:-1])) \
                 <= 1e-10 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("nproc", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
+@pytest.mark.parametrize("kind,L", [("const", 2), ("var", 1), ("offdiag", 2)])
+def test_cartesian_schedule_reproduces_the_undivided_solve(orc, tmp_path, kind, L, nproc):
+    """Sub-domains in x and y too (up to the reference driver's 2 x 2 x 2): exchange
+    order x, y, z over full tangential boxes, vector updates carried on all ghost
+    layers, interface points shared with weights 1/2, 1/4, 1/8."""
+    from helpers import oracle_solve
+    p = make_problem(kind)
+    want = oracle_solve(orc, p, L=L, eps=1e-30, max_outer=4)
+    world = nproc[0] * nproc[1] * nproc[2]
+    mp.start_processes(brick_worker, args=(world, free_port(), kind, L, nproc, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    m = [p.mx[d] // nproc[d] for d in range(3)]
+    for r in range(world):
+        c = (r // (nproc[1] * nproc[2]), (r // nproc[2]) % nproc[1], r % nproc[2])
+        d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert float(d["nrhs"]) == pytest.approx(want["norm_rhs"], rel=1e-13)
+        assert np.max(np.abs(d["hist"] - want["history"][:4])) <= 1e-10 * want["norm_rhs"]
+        mine = d["phi"][1:-1, 1:-1, 1:-1]
+        ref = want["phi"][c[2] * m[2] + 1: c[2] * m[2] + m[2] + 2, c[1] * m[1] + 1: c[1] * m[1] + m[1] + 2,
+                          c[0] * m[0] + 1: c[0] * m[0] + m[0] + 2]
+        assert np.max(np.abs(mine - ref)) <= 1e-10 * np.max(np.abs(ref))
