@@ -102,3 +102,21 @@ def test_benchmark_grid_512_fused_against_one_kernel_per_primitive(workload, pas
     a, b = hist
     assert len(a) == len(b) == passes
     assert np.max(np.abs(a - b) / np.abs(b)) <= tol
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_eight_gpu_slab_shape_split_launch(monkeypatch, overlap):
+    """The slab an 8-GPU run of the 512^3 benchmark gives each GPU (512 x 512 x 64):
+    chunking, edge/interior split of the stencil kernels and the overlapped exchange
+    as they will run there, here with two such slabs against the undivided 512 x 512 x 128 grid."""
+    import bench
+    monkeypatch.setenv("KRY_OVERLAP", overlap)
+    f = bench.slab_problem(512, 1, 0, "var", nz=128)
+    hist = []
+    for ns in (1, 2):
+        with capi.Solver(f["mx"], f["delx"], f["bc"], L=2, eps=0.0, nslabs=ns, slab_count=ns, devices=(0,)) as s:
+            s.load_var(f["phi"], f["rhs"], f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False)
+            assert s.iterate(4) == 0 and s.stats().fused == 1
+            hist.append(s.history())
+            assert s.stats().chunk_planes == (16 if ns == 2 else s.stats().chunk_planes)
+    assert np.max(np.abs(hist[0] - hist[1]) / hist[0]) <= 1e-10
