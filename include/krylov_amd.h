@@ -47,7 +47,8 @@ enum {
 /* flags */
 enum {
 	KRY_FORCE_GENERIC = 1,   /* run the one-kernel-per-primitive path even when the fused path applies */
-	KRY_NO_GRAPH      = 2    /* reserved */
+	KRY_NO_GRAPH      = 2    /* never replay pairs of passes as a HIP graph (the default; KRY_GRAPH=1 in the
+	                            environment turns the replay on for single-slab runs) */
 };
 
 typedef struct kry_desc {

@@ -124,6 +124,13 @@ struct kry_solver {
 	double solve_ms = 0, stage_ms = 0;
 	double enqueue_ms = 0;     // host time spent queueing the passes of the last run
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
+	// two consecutive passes (even, odd: the ping-pong buffers swap roles) captured as a
+	// HIP graph: one launch call per pair instead of 6-20 kernel launches.  Off unless
+	// KRY_GRAPH=1: the passes are chains of dependent, GPU-bound kernels queued far
+	// ahead of the device, and replaying them as a graph measured 0 to -2 % from 32^3
+	// to 512^3.
+	hipGraphExec_t pass_pair = nullptr;
+	bool use_graph = false;
 	std::vector<double> step_ms;   // wall time per pass (a batch's time spread evenly over its passes)
 	bool profile = false;
 	bool overlap = true;       // halo exchange concurrent with the interior chunks
@@ -1091,6 +1098,42 @@ int prologue(kry_solver *h)
 	return 0;
 }
 
+void drop_graph(kry_solver *h)
+{
+	if (h->pass_pair) {
+		hipSetDevice(h->slabs[0].device);
+		hipGraphExecDestroy(h->pass_pair);
+	}
+	h->pass_pair = nullptr;
+}
+
+// Capture passes 0 and 1 of the loaded problem (kernel arguments depend on the pass
+// parity only; all scalars live in device memory).  Single slab, no profiling events.
+int build_graph(kry_solver *h)
+{
+	Slab &s = h->slabs[0];
+	HIPCHK(hipSetDevice(s.device));
+	hipGraph_t g = nullptr;
+	HIPCHK(hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal));
+	int st = fused_pass(h, 0);
+	if (st == 0) st = fused_pass(h, 1);
+	hipError_t e = hipStreamEndCapture(s.st, &g);
+	if (st != 0 || e != hipSuccess || !g) {
+		if (g) hipGraphDestroy(g);
+		(void)hipGetLastError();
+		h->use_graph = false;      // run with plain launches
+		return 0;
+	}
+	e = hipGraphInstantiate(&h->pass_pair, g, nullptr, nullptr, 0);
+	hipGraphDestroy(g);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		h->pass_pair = nullptr;
+		h->use_graph = false;
+	}
+	return 0;
+}
+
 int run_iterations(kry_solver *h, int n_outer)
 {
 	if (!h->loaded) { set_err("kry_iterate: no problem loaded"); return KRY_ERR_STATE; }
@@ -1109,7 +1152,18 @@ int run_iterations(kry_solver *h, int n_outer)
 			int nb = (n_outer <= 0) ? batch_max : std::min(batch_max, left);
 			const int it0 = h->it_base;
 			double t0 = now_ms();
-			for (int i = 0; i < nb; ++i) CHK(fused_pass(h, it0 + i));
+			const bool graph_ok = h->use_graph && !h->profile && h->slabs.size() == 1 && !h->comm.active() &&
+			                      h->debug <= 2;
+			if (graph_ok && !h->pass_pair) CHK(build_graph(h));
+			for (int i = 0; i < nb;) {
+				if (graph_ok && h->pass_pair && ((it0 + i) & 1) == 0 && i + 1 < nb) {
+					HIPCHK(hipGraphLaunch(h->pass_pair, h->slabs[0].st));
+					i += 2;
+				} else {
+					CHK(fused_pass(h, it0 + i));
+					i += 1;
+				}
+			}
 			h->enqueue_ms += now_ms() - t0;
 			CHK(poll_state(h));
 			{
@@ -1166,6 +1220,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 		return KRY_ERR_ARG;
 	}
 	double t0 = now_ms();
+	drop_graph(h);
 	h->var = var;
 	h->offd = var && offd;
 	make_op(h, var, Dc);
@@ -1300,6 +1355,8 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	if (const char *e = getenv("KRY_STREAM_BLOCKS")) h->stream_blocks = std::max(64, atoi(e));
 	if (const char *e = getenv("KRY_OVERLAP")) h->overlap = atoi(e) != 0;
 	if (const char *e = getenv("KRY_PROFILE")) h->profile = atoi(e) != 0;
+	if (const char *e = getenv("KRY_GRAPH")) h->use_graph = atoi(e) != 0;
+	if (d->flags & KRY_NO_GRAPH) h->use_graph = false;
 	h->slabs.resize(d->slab_count);
 	int st = 0;
 	auto build = [&]() -> int {
@@ -1389,6 +1446,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 void kry_destroy(kry_handle h)
 {
 	if (!h) return;
+	drop_graph(h);
 	h->comm.destroy();
 	for (Slab &s : h->slabs) {
 		hipSetDevice(s.device);

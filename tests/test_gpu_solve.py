@@ -156,3 +156,22 @@ def test_fields_may_live_in_device_memory(orc):
     for d in dev:
         L.hipFree(d)
     assert np.array_equal(phi, ref["phi"])
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_graph_replay_of_pass_pairs_changes_nothing(monkeypatch, L):
+    """KRY_GRAPH=1 replays two captured passes per launch call; odd starts, odd
+    batch lengths and the tail fall back to plain launches.  Same bits either way."""
+    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1)) if L == 2 else P.reference_test1(24)
+    plain = capi.solve_problem(p, L=L, eps=1e-9)
+    monkeypatch.setenv("KRY_GRAPH", "1")
+    graph = capi.solve_problem(p, L=L, eps=1e-9)
+    assert np.array_equal(plain["history"], graph["history"]) and len(plain["history"]) > 8
+    assert np.array_equal(plain["phi"], graph["phi"])
+    with capi.Solver(p.mx, p.delx, p.bc, L=L, eps=0.0) as s:      # resumed stepping with odd counts
+        load = (lambda: s.load_var(p.phi, p.rhs, p.lam, p.Dxx, p.Dyy, p.Dzz, None, False)) if p.var_coef else \
+               (lambda: s.load_const(p.phi, p.rhs, p.lam, p.Dc))
+        load()
+        for n in (3, 1, 4, 5):
+            assert s.iterate(n) == 0
+        assert np.array_equal(s.history(), plain["history"][:13]) or len(plain["history"]) < 13
