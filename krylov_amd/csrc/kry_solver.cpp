@@ -1433,7 +1433,8 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		const KryGeo &g = h->slabs[0].g;
 		const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + h->ty - 1) / h->ty);
 		const int chunks = std::max(1, (1024 + tiles - 1) / tiles);
-		h->zc = std::min(64, std::max(8, (g.mz + chunks - 1) / chunks));
+		// (small grids: short chunks, the march over a chunk's planes is a latency chain)
+		h->zc = std::min(64, std::max(g.mz <= 64 ? 2 : 4, (g.mz + chunks - 1) / chunks));
 	}
 	if (st < 0) {
 		kry_destroy(h);
