@@ -30,6 +30,21 @@
 
 static int g_mode = 0;          /* 0 off, 1 fused Dirichlet path, 2 generic path, 3 fused general-boundary path */
 static int g_ty = 8, g_zc = 16, g_sb = 2048;
+static int g_nslabs = 1;        /* z slabs of the device run (sums are formed per slab, then added in slab order) */
+static int g_split = 0;         /* 1: the stencil kernels of a multi-slab run are launched in two parts (edge chunks first) */
+
+/* one z slab of the global box: local plane k is global plane z0 + k */
+typedef struct { int z0, mz, has_lo, has_hi; } zslab;
+static zslab slab_of(const orc_cfg *c, int s)
+{
+	zslab q;
+	q.mz = c->mx[2] / g_nslabs;
+	q.z0 = s * q.mz;
+	q.has_lo = s > 0;
+	q.has_hi = s < g_nslabs - 1;
+	return q;
+}
+
 
 typedef struct { int mx, my, mz; long sx, sy; } hbox;
 static hbox hb(const orc_cfg *c)
@@ -69,20 +84,50 @@ static double grid_total(const double *partial, long nblk)
 	return block_total(tot);
 }
 
-/* fused stencil kernels: k_fused */
-static double fused_sum(const orc_cfg *c, const double *A, const double *B)
+/* block index of a launch of nb blocks -> tile index (the XCD-aware map of k_fused) */
+static long swizzle(long bp, long nb)
+{
+	const long q = nb >> 3, r = nb & 7, x = bp & 7;
+	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
+}
+
+/* fused stencil kernels: k_fused, on one slab */
+static int fused_geometry(const orc_cfg *c, zslab sl, int *nchunk, int *n_edge)
+{
+	const int zlo = sl.has_lo ? 0 : 1, zhi = sl.has_hi ? sl.mz : sl.mz - 1;
+	*nchunk = (zhi - zlo + 1 + g_zc - 1) / g_zc;
+	const int c_hi = (sl.mz - 1 - zlo) / g_zc;
+	*n_edge = (c_hi == *nchunk - 1) ? 2 : 3;
+	(void)c;
+	return *nchunk > *n_edge;
+}
+
+static double fused_sum_slab(const orc_cfg *c, const double *A, const double *B, zslab sl, int split)
 {
 	const hbox b = hb(c);
 	const int ty = g_ty, zc = g_zc, VD = ty / NW;
 	const int ntx = (b.mx + 127) / 128, nty = (b.my + ty - 1) / ty;
-	const int zlo = 1, zhi = b.mz - 1;
-	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
-	const long nblk = (long)ntx * nty * nchunk;
+	const int zlo = sl.has_lo ? 0 : 1, zhi = sl.has_hi ? sl.mz : sl.mz - 1;
+	/* split launch: chunk 0 and the last n_edge-1 chunks first, the rest second (kry_solver.cpp, stencil_step) */
+	int nchunk, n_edge;
+	fused_geometry(c, sl, &nchunk, &n_edge);
+	const long tiles = (long)ntx * nty, nblk = tiles * nchunk;
 	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
-	for (long bp = 0; bp < nblk; ++bp) {
-		const long q = nblk >> 3, r = nblk & 7, x = bp & 7;
-		const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
-		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
+	for (long pi = 0; pi < nblk; ++pi) {
+		long bid;
+		int ch;
+		if (!split) {
+			bid = swizzle(pi, nblk);
+			ch = (int)(bid / tiles);
+		} else if (pi < n_edge * tiles) {
+			bid = swizzle(pi, n_edge * tiles);
+			ch = (int)(bid / tiles);
+			ch = ch ? nchunk - n_edge + ch : 0;
+		} else {
+			bid = swizzle(pi - n_edge * tiles, (nchunk - n_edge) * tiles);
+			ch = (int)(bid / tiles) + 1;
+		}
+		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty);
 		const int z0 = zlo + ch * zc;
 		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
 		const int y0 = tyi * ty;
@@ -95,25 +140,45 @@ static double fused_sum(const orc_cfg *c, const double *A, const double *B)
 				for (int e = 0; e < VD; ++e) {
 					const int j = y0 + w * VD + e;
 					if (j < 1 || j > b.my - 1 || z < 1) continue;
-					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, z) * HAT(b, B, i0, j, z);
-					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, z) * HAT(b, B, i0 + 1, j, z);
+					const int zg = sl.z0 + z;
+					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, zg) * HAT(b, B, i0, j, zg);
+					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, zg) * HAT(b, B, i0 + 1, j, zg);
 				}
 			acc[t] = s;
 		}
-		partial[bp] = block_total(acc);
+		partial[pi] = block_total(acc);
 	}
 	double v = grid_total(partial, nblk);
 	free(partial);
 	return v;
 }
 
-/* streaming kernels: k_final, k_mgs2 */
-static double stream_sum(const orc_cfg *c, const double *A, const double *B, int min_planes)
+static double fused_sum_opt(const orc_cfg *c, const double *A, const double *B, int may_split)
+{
+	/* the launches are split only when every slab has chunks between its edge chunks */
+	int split = may_split && g_split && g_nslabs > 1;
+	for (int s = 0; s < g_nslabs && split; ++s) {
+		int nc, ne;
+		split = fused_geometry(c, slab_of(c, s), &nc, &ne);
+	}
+	double v = fused_sum_slab(c, A, B, slab_of(c, 0), split);
+	for (int s = 1; s < g_nslabs; ++s) v += fused_sum_slab(c, A, B, slab_of(c, s), split);
+	return v;
+}
+
+static double fused_sum(const orc_cfg *c, const double *A, const double *B) { return fused_sum_opt(c, A, B, 1); }
+/* the residual kernel of the prologue is launched in one part */
+static double fused_sum_whole(const orc_cfg *c, const double *A, const double *B) { return fused_sum_opt(c, A, B, 0); }
+
+/* streaming kernels: k_final, k_mgs2, on one slab */
+static double stream_sum_slab(const orc_cfg *c, const double *A, const double *B, int min_planes, zslab sl)
 {
 	const hbox b = hb(c);
 	const long px = ((b.mx + 4 + 15) / 16) * 16, ps = px * (b.my + 3);
 	const int nbx = (int)((ps + 2047) / 2048);
-	const int nplanes = b.mz - 1;
+	const int zfirst = sl.has_lo ? -1 : 1, zlast = sl.has_hi ? sl.mz + 1 : sl.mz - 1;
+	const int nplanes = zlast - zfirst + 1;
+	const int cnt_lo = 1, cnt_hi = sl.has_hi ? sl.mz : sl.mz - 1;
 	int nby = (g_sb + nbx - 1) / nbx;
 	const int cap = nplanes / min_planes > 1 ? nplanes / min_planes : 1;   /* planes per block: 4 in k_mgs2, 1 in k_final */
 	if (nby > cap) nby = cap;
@@ -126,7 +191,8 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B, int
 			for (int t = 0; t < NT; ++t) {
 				double s = 0.;
 				for (int pl = by; pl < nplanes; pl += nby) {
-					const int z = 1 + pl;
+					const int z = zfirst + pl;
+					if (z < cnt_lo || z > cnt_hi) continue;
 					for (int i = 0; i < 4; ++i) {
 						const long q = 2 * ((long)bx * 1024 + i * NT + t);
 						if (q >= ps) break;
@@ -134,7 +200,7 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B, int
 							const long qq = q + d + 2;   /* the kernels start a plane at column 2 */
 							const int jj = (int)(qq / px) - 1, ii = (int)(qq % px) - 2;
 							if (ii >= 1 && ii <= b.mx - 1 && jj >= 1 && jj <= b.my - 1 && qq < ps)
-								s += HAT(b, A, ii, jj, z) * HAT(b, B, ii, jj, z);
+								s += HAT(b, A, ii, jj, sl.z0 + z) * HAT(b, B, ii, jj, sl.z0 + z);
 						}
 					}
 				}
@@ -147,34 +213,43 @@ static double stream_sum(const orc_cfg *c, const double *A, const double *B, int
 	return v;
 }
 
+static double stream_sum(const orc_cfg *c, const double *A, const double *B, int min_planes)
+{
+	double v = stream_sum_slab(c, A, B, min_planes, slab_of(c, 0));
+	for (int s = 1; s < g_nslabs; ++s) v += stream_sum_slab(c, A, B, min_planes, slab_of(c, s));
+	return v;
+}
+
 /* ---- general-boundary fused path ---- */
 
-static double face_weight(const hbox *b, int i, int j, int k)
+/* weight of local point (i,j,k) of a slab: 1/2 per face of the GLOBAL domain it lies on */
+static double face_weight(const hbox *b, zslab sl, int i, int j, int k)
 {
-	const int fx = (i == 0 || i == b->mx), fy = (j == 0 || j == b->my), fz = (k == 0 || k == b->mz);
+	const int fx = (i == 0 || i == b->mx), fy = (j == 0 || j == b->my);
+	const int fz = (k == 0 && !sl.has_lo) || (k == sl.mz && !sl.has_hi);
 	return (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
 }
 
 /* k_fused<GEN> (tiles start at i = 0 and row j = -1, planes 0..mz, strict interior
- * counted) followed by k_surf (boundary planes, weighted), one reduction over both */
-static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
+ * counted) followed by k_surf (boundary planes, weighted), one reduction over both; on one slab */
+static double fused_gen_sum_slab(const orc_cfg *c, const double *A, const double *B, zslab sl)
 {
 	const hbox b = hb(c);
 	const int ty = 8, zc = g_zc, VD = ty / NW;
 	const int ntx = (b.mx + 127) / 128, nty = (b.my + 3 + ty - 1) / ty;
-	const int zlo = 0, zhi = b.mz;
+	const int zlo = 0, zhi = sl.mz;
 	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
 	const long nf = (long)ntx * nty * nchunk;
 	const long nxy = (long)(b.mx + 1) * (b.my + 1);
-	const int k1 = 1, nk = b.mz - 1;
-	const long tz = 2 * nxy, tyy = 2L * nk * (b.mx + 1), txx = 2L * nk * (b.my - 1), total = tz + tyy + txx;
+	const int nzf = (sl.has_lo ? 0 : 1) + (sl.has_hi ? 0 : 1);
+	const int k1 = 1, k2 = sl.has_hi ? sl.mz : sl.mz - 1, nk = k2 - k1 + 1;
+	const long tz = nzf * nxy, tyy = 2L * nk * (b.mx + 1), txx = 2L * nk * (b.my - 1), total = tz + tyy + txx;
 	long ns = (total + 255) / 256;
 	if (ns > 512) ns = 512;
 	if (ns < 1) ns = 1;
 	double *partial = (double *)malloc((size_t)(nf + ns) * sizeof(double));
 	for (long bp = 0; bp < nf; ++bp) {
-		const long q = nf >> 3, r = nf & 7, x = bp & 7;
-		const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
+		const long bid = swizzle(bp, nf);
 		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
 		const int z0 = zlo + ch * zc;
 		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
@@ -187,9 +262,10 @@ static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 			for (int z = z0; z < z1; ++z)
 				for (int e = 0; e < VD; ++e) {
 					const int j = y0 + w * VD + e;
-					if (j < 1 || j > b.my - 1 || z < 1 || z > b.mz - 1) continue;
-					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, z) * HAT(b, B, i0, j, z);
-					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, z) * HAT(b, B, i0 + 1, j, z);
+					if (j < 1 || j > b.my - 1 || z < 1 || z > k2) continue;
+					const int zg = sl.z0 + z;
+					if (i0 >= 1 && i0 <= b.mx - 1) s += HAT(b, A, i0, j, zg) * HAT(b, B, i0, j, zg);
+					if (i0 + 1 >= 1 && i0 + 1 <= b.mx - 1) s += HAT(b, A, i0 + 1, j, zg) * HAT(b, B, i0 + 1, j, zg);
 				}
 			acc[t] = s;
 		}
@@ -206,7 +282,7 @@ static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 					const long rem = t - f * nxy;
 					j = (int)(rem / (b.mx + 1));
 					i = (int)(rem - (long)j * (b.mx + 1));
-					k = f ? b.mz : 0;
+					k = (f == 0 && !sl.has_lo) ? 0 : sl.mz;
 				} else if (t < tz + tyy) {
 					const long rem = t - tz, r2 = rem / (b.mx + 1);
 					i = (int)(rem - r2 * (b.mx + 1));
@@ -218,7 +294,7 @@ static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 					i = (r2 & 1) ? b.mx : 0;
 					k = k1 + (int)(r2 >> 1);
 				}
-				s += face_weight(&b, i, j, k) * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
+				s += face_weight(&b, sl, i, j, k) * (HAT(b, A, i, j, sl.z0 + k) * HAT(b, B, i, j, sl.z0 + k));
 			}
 			acc[t0] = s;
 		}
@@ -229,13 +305,22 @@ static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
 	return v;
 }
 
-/* k_final<GEN>, k_mgs2<GEN>: planes -1..mz+1, weighted points */
-static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B, int min_planes, int norm_mode)
+static double fused_gen_sum(const orc_cfg *c, const double *A, const double *B)
+{
+	double v = fused_gen_sum_slab(c, A, B, slab_of(c, 0));
+	for (int s = 1; s < g_nslabs; ++s) v += fused_gen_sum_slab(c, A, B, slab_of(c, s));
+	return v;
+}
+
+/* k_final<GEN>, k_mgs2<GEN>: planes -1..mz+1, weighted points; on one slab */
+static double stream_gen_sum_slab(const orc_cfg *c, const double *A, const double *B, int min_planes, int norm_mode,
+                                  zslab sl)
 {
 	const hbox b = hb(c);
 	const long px = ((b.mx + 4 + 15) / 16) * 16, ps = px * (b.my + 3);
 	const int nbx = (int)((ps + 2047) / 2048);
-	const int nplanes = b.mz + 3;
+	const int nplanes = sl.mz + 3;
+	const int cnt_lo = sl.has_lo ? 1 : 0, cnt_hi = sl.mz;
 	int nby = (g_sb + nbx - 1) / nbx;
 	const int cap = nplanes / min_planes > 1 ? nplanes / min_planes : 1;
 	if (nby > cap) nby = cap;
@@ -249,7 +334,7 @@ static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B,
 				double s = 0.;
 				for (int pl = by; pl < nplanes; pl += nby) {
 					const int z = -1 + pl;
-					if (z < 0 || z > b.mz) continue;
+					if (z < cnt_lo || z > cnt_hi) continue;
 					for (int i = 0; i < 4; ++i) {
 						const long q = 2 * ((long)bx * 1024 + i * NT + t);
 						if (q >= ps) break;
@@ -257,9 +342,9 @@ static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B,
 							const long qq = q + d + 2;
 							const int jj = (int)(qq / px) - 1, ii = (int)(qq % px) - 2;
 							if (ii < 0 || ii > b.mx || jj < 0 || jj > b.my) continue;
-							double wgt = face_weight(&b, ii, jj, z);
+							double wgt = face_weight(&b, sl, ii, jj, z);
 							if (norm_mode && wgt == 0.125) wgt = 0.25;
-							s += wgt * (HAT(b, A, ii, jj, z) * HAT(b, B, ii, jj, z));
+							s += wgt * (HAT(b, A, ii, jj, sl.z0 + z) * HAT(b, B, ii, jj, sl.z0 + z));
 						}
 					}
 				}
@@ -272,12 +357,19 @@ static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B,
 	return v;
 }
 
+static double stream_gen_sum(const orc_cfg *c, const double *A, const double *B, int min_planes, int norm_mode)
+{
+	double v = stream_gen_sum_slab(c, A, B, min_planes, norm_mode, slab_of(c, 0));
+	for (int s = 1; s < g_nslabs; ++s) v += stream_gen_sum_slab(c, A, B, min_planes, norm_mode, slab_of(c, s));
+	return v;
+}
+
 /* generic weighted dot: g_wdot (wave w of block b walks grid rows 4b+w, +4*nblk, ...;
- * a lane takes points lane, lane+64, ... of each row) */
-static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int norm_mode)
+ * a lane takes points lane, lane+64, ... of each row), on one slab */
+static double wdot_sum_slab(const orc_cfg *c, const double *A, const double *B, int norm_mode, zslab sl)
 {
 	const hbox b = hb(c);
-	const long rows = (long)(b.my + 1) * (b.mz + 1);
+	const long rows = (long)(b.my + 1) * (sl.mz + 1);
 	long nblk = (rows + NW - 1) / NW;
 	if (nblk > 4096) nblk = 4096;
 	double *partial = (double *)malloc((size_t)nblk * sizeof(double));
@@ -288,12 +380,14 @@ static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int n
 			double s = 0.;
 			for (long row = blk * NW + w; row < rows; row += nblk * NW) {
 				const int j = (int)(row % (b.my + 1)), k = (int)(row / (b.my + 1));
-				const int fy = (j == 0 || j == b.my), fz = (k == 0 || k == b.mz);
+				if (k == 0 && sl.has_lo) continue;      /* counted by the lower slab */
+				const int fy = (j == 0 || j == b.my);
+				const int fz = (k == 0 && !sl.has_lo) || (k == sl.mz && !sl.has_hi);
 				for (int i = lane; i <= b.mx; i += 64) {
 					const int fx = (i == 0 || i == b.mx);
 					double wgt = (fx ? 0.5 : 1.) * (fy ? 0.5 : 1.) * (fz ? 0.5 : 1.);
 					if (norm_mode && fx && fy && fz) wgt = 0.25;
-					s += wgt * (HAT(b, A, i, j, k) * HAT(b, B, i, j, k));
+					s += wgt * (HAT(b, A, i, j, sl.z0 + k) * HAT(b, B, i, j, sl.z0 + k));
 				}
 			}
 			acc[t] = s;
@@ -302,6 +396,13 @@ static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int n
 	}
 	double v = grid_total(partial, nblk);
 	free(partial);
+	return v;
+}
+
+static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int norm_mode)
+{
+	double v = wdot_sum_slab(c, A, B, norm_mode, slab_of(c, 0));
+	for (int s = 1; s < g_nslabs; ++s) v += wdot_sum_slab(c, A, B, norm_mode, slab_of(c, s));
 	return v;
 }
 
@@ -330,9 +431,9 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 	}
 	switch (site) {
 	case ORC_SITE_NORM_RHS:  return sqrt(wdot_sum(c, a, b, 1));
-	case ORC_SITE_NORM_INIT: return sqrt(fused_sum(c, a, b));          /* residual kernel */
+	case ORC_SITE_NORM_INIT: return sqrt(fused_sum_whole(c, a, b));    /* residual kernel */
 	case ORC_SITE_RHO:
-		if (jj == 0) return iter == 1 ? fused_sum(c, a, b)                /* |r0|^2 of the residual kernel */
+		if (jj == 0) return iter == 1 ? fused_sum_whole(c, a, b)          /* |r0|^2 of the residual kernel */
 		                              : stream_sum(c, a, b, 1);           /* end-of-pass kernel */
 		return fused_sum(c, a, b);                                        /* B kernel of jj-1 */
 	case ORC_SITE_ALPHA:     return fused_sum(c, a, b);                   /* A kernels */
@@ -342,6 +443,12 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b, 1));
 	}
 	return orc_dot(c, a, b);
+}
+
+void orc_gpu_order_slabs(int nslabs, int split_launch)
+{
+	g_nslabs = nslabs > 0 ? nslabs : 1;
+	g_split = split_launch != 0;
 }
 
 void orc_use_gpu_order(int enable, int ty, int zc, int stream_blocks)

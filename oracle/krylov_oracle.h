@@ -82,6 +82,10 @@ void orc_set_reduce_hook(orc_reduce_hook hook, void *ctx);
  * `ty`, planes per chunk `zc`, streaming-kernel grid target `stream_blocks`);
  * enable = 0 switches back to the reference order. */
 void orc_use_gpu_order(int enable, int ty, int zc, int stream_blocks);
+/* The device run used `nslabs` z slabs (per-slab sums added in slab order);
+ * split_launch: its stencil kernels ran in two parts, edge chunks first (fused
+ * Dirichlet path; the general-boundary path never splits).  Defaults: 1, 0. */
+void orc_gpu_order_slabs(int nslabs, int split_launch);
 
 /* Building blocks, exported for kernel-level parity tests. */
 void   orc_do_bcs(const orc_cfg *cfg, double *a);

@@ -89,6 +89,8 @@ def lib():
         L.orc_really_is_nan.argtypes = [C.c_double]
         L.orc_use_gpu_order.restype = None
         L.orc_use_gpu_order.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_gpu_order_slabs.restype = None
+        L.orc_gpu_order_slabs.argtypes = [C.c_int, C.c_int]
         L.orc_store_size.restype = C.c_long
         L.orc_store_size.argtypes = [P(OrcCfg)]
         _lib = L
@@ -158,6 +160,12 @@ def use_gpu_order(mode, ty=8, zc=16, stream_blocks=2048):
     path; 2: order of the generic device path; 3: order of the fused
     general-boundary device path (see gpu_order.c)."""
     lib().orc_use_gpu_order(int(mode), int(ty), int(zc), int(stream_blocks))
+
+
+def gpu_order_slabs(nslabs=1, split_launch=False):
+    """The device run to reproduce used `nslabs` z slabs; split_launch: with the
+    edge/interior split of its stencil kernels (overlapped halo exchange)."""
+    lib().orc_gpu_order_slabs(int(nslabs), int(bool(split_launch)))
 
 
 def really_is_nan(x):

@@ -43,13 +43,15 @@ def make(kind, n):
     raise KeyError(kind)
 
 
-def run_pair(orc, p, L, eps, max_outer, flags=0):
-    got = capi.solve_problem(p, L=L, eps=eps, max_outer=max_outer, flags=flags)
+def run_pair(orc, p, L, eps, max_outer, flags=0, nslabs=1, split=False):
+    got = capi.solve_problem(p, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs_local=nslabs, devices=(0,))
     ty, zc, sb = got["order"]
     orc.use_gpu_order({0: 2, 1: 1, 2: 3}[got["path"]], ty, zc, sb)
+    orc.gpu_order_slabs(nslabs, split)
     try:
         want = oracle_solve(orc, p, L=L, eps=eps, max_outer=max_outer)
     finally:
+        orc.gpu_order_slabs(1, False)
         orc.use_gpu_order(0)
     return want, got
 
@@ -92,6 +94,47 @@ def test_generic_path_matches_oracle_in_device_order(orc, bc, L):
     want, got = run_pair(orc, p, L, eps=1e-13, max_outer=50, flags=capi.KRY_FORCE_GENERIC)
     assert not got["fused"]
     assert_identical(want, got, min_passes=50 // L if L > 2 else 50)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("nslabs", [2, 4])
+@pytest.mark.parametrize("kind,n,L", [("const_random_rhs", 32, 1), ("const_random_rhs", 32, 2), ("var_random_rhs", 48, 2),
+                                      ("offdiag", 32, 1), ("var_random_rhs", (40, 24, 64), 2)])
+def test_slab_runs_match_oracle_in_device_order(orc, monkeypatch, kind, n, L, nslabs, overlap):
+    """Several z slabs (per-slab sums added in slab order; with KRY_OVERLAP=1 and short
+    chunks also the edge/interior split of the stencil launches): still bit for bit."""
+    monkeypatch.setenv("KRY_OVERLAP", overlap)
+    monkeypatch.setenv("KRY_ZC", "4")
+    if isinstance(n, tuple):
+        rng = np.random.default_rng(17)
+        p = P.smooth_var(n)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    else:
+        p = make(kind, n)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=40, nslabs=nslabs, split=(overlap == "1"))
+    assert got["fused"]
+    assert_identical(want, got, min_passes=10)
+
+
+@pytest.mark.parametrize("nslabs", [2, 4])
+@pytest.mark.parametrize("L", [1, 3])
+def test_generic_path_slab_runs_match_oracle_in_device_order(orc, nslabs, L):
+    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
+    p.rhs = np.random.default_rng(3).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=30, flags=capi.KRY_FORCE_GENERIC, nslabs=nslabs)
+    assert got["path"] == 0
+    assert_identical(want, got, min_passes=10)
+
+
+@pytest.mark.parametrize("nslabs", [2, 4])
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("bc", [(0, 0, 1, 1, 0, 1), (1, 1, 0, 1, 1, 1)])
+def test_general_boundary_slab_runs_match_oracle_in_device_order(orc, bc, L, nslabs):
+    p = P.smooth_var((24, 20, 32), bc=bc)
+    p.rhs = np.random.default_rng(3).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=30, nslabs=nslabs)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=10)
 
 
 MIXED = [(0, 0, 1, 1, 0, 1), (1, 0, 0, 1, 1, 0), (1, 1, 1, 1, 1, 1), (0, 0, 0, 0, 1, 1), (0, 1, 0, 0, 0, 0)]
