@@ -85,6 +85,10 @@ def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     # every rank holds the same history, bit for bit
     for d in parts[1:]:
         assert np.array_equal(d["hist"], parts[0]["hist"])
+    # and it is the history of one process driving the same slabs (the transport adds the
+    # per-slab sums in rank order, as the library does for its own slabs)
+    same = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, flags=flags, nslabs_local=world, devices=(0,))
+    assert np.array_equal(parts[0]["hist"], same["history"])
 
 
 @gpu
