@@ -583,11 +583,23 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 			a.red.nblk = a.nblk + nsurf;
 			CHK(launch_fused(h, s, kind, a, 1));
 			HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));   // the z faces follow in k_surf
+		}
+		// planes 1 and mz-1, the ones the z neighbours need, are final once the x and y faces
+		// are treated: their exchange runs beside k_surf (z faces, boundary-plane dot terms)
+		const bool beside = multi && h->overlap && !h->cart;
+		if (beside) CHK(exchange_halo_begin(h, outs));
+		for (int i = 0; i < ns; ++i) {
+			Slab &s = h->slabs[i];
+			KryFused a = args[i];
+			const int nsurf = surf_blocks(s.g);
+			a.red.nblk = a.nblk + nsurf;
 			a.blk_off = a.nblk;
+			HIPCHK(hipSetDevice(s.device));
 			HIPCHK(kry_launch_surf(kind, a, nsurf, s.st));
 			prof_end(h, s);
 		}
-		if (multi) CHK(exchange_halo(h, outs));
+		if (beside) CHK(exchange_halo_end(h));
+		else if (multi) CHK(exchange_halo(h, outs));
 		return 0;
 	}
 	// the neighbours need planes 1 and mz-1: chunk 0 and the chunk holding plane mz-1
