@@ -415,8 +415,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const long coff = (long)(y0 + crr - 1 + 1) * g.px + ccol;
 	const int cl = crr * LW + (cside ? 130 : 1);
 	// halo-column cells that are ghost / face cells of this tile's rows: updated here
+	// (behind a Dirichlet face of the domain these cells are zero and stay zero under every update)
 	const bool cstore = GEN && hcol && crr >= 1 && crr <= TY && (y0 + crr - 1) <= g.my + 1 &&
-	                    (cside ? (tx == a.ntx - 1 && ccol - 2 <= g.mx + 1) : tx == 0);
+	                    (cside ? (tx == a.ntx - 1 && ccol - 2 <= g.mx + 1 && (g.nb[1] || g.bc[1] != 0))
+	                           : (tx == 0 && (g.nb[0] || g.bc[0] != 0)));
 
 	double2 pm[VD], pc[VD], pp[VD];
 	double2 dzm[VD], dzc[VD], dzp[VD];
