@@ -166,6 +166,16 @@ def cpu_baseline(n_sample, L, workload, n_full, budget_iters):
     return out
 
 
+def claim_stdout():
+    """Routes file descriptor 1 to stderr for the rest of the run and returns a
+    descriptor of the real stdout: libraries underneath (gloo, RCCL) print start-up
+    notes on fd 1, and stdout must carry the one JSON line only."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +192,7 @@ def main():
     ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=192)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
+    real_stdout = claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -318,7 +329,7 @@ def main():
         }
         if world == 1 and not args.no_cpu and not args.weak:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, L, args.workload, n, args.cpu_iters)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     solver.close()
     if dist is not None:
