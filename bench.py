@@ -42,12 +42,12 @@ def kernel_words(L, var, offd):
         return {0: 7 + d,          # r0,u0,u1(old),lam,rt -> u0,u1
                 3: 5 + d,          # r0,u1,lam -> r0,r1
                 7: 7}              # phi,u0,r0,r1,rt -> phi,r0   (the u0 update rides in the next pass's first kernel)
-    return {0: 8 + d,              # r0,u0,u1(old),u2(old),lam,rt -> u0,u1
+    return {0: 6 + d,              # r0,u0,lam,rt -> u0,u1
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
             1: 6 + d,              # r1,u1,lam,rt -> u1,u2
             4: 7 + d,              # r1,u2,lam,r0,u1 -> r1,r2
             6: 4,                  # r2,r1,r0,u1 -> dots only (r2' and r0'' are recomputed by the last kernel)
-            7: 10}                 # phi,r0..r2,u0,u1,rt -> phi,r0,u0
+            7: 11}                 # phi,r0..r2,u0,u1,u2,rt -> phi,r0,u0
 
 
 def measured_traffic(kernel_name, n, L, workload, world):

@@ -10,7 +10,7 @@
 
 // fused stencil kernel kinds
 enum KryFusedKind {
-	KF_A0 = 0,   // [u0 -= gamma_L*u_L (- gamma_1*u_1), deferred from the last pass] ; u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
+	KF_A0 = 0,   // [l = 1: u0 -= gamma_1*u_1, deferred from the last pass] ; u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
 	KF_A1,       // l=2, jj=1: u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)   (phi and u0 of this step: k_final)
 	KF_B0,       // l=2, jj=0: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 	KF_B0L,      // l=1:       r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
@@ -35,7 +35,7 @@ struct KryFused {
 	KryState *S;
 	const double *X, *Y;     // psi = X + Y*c  (c = -beta for A kinds, -alpha for B kinds)
 	const double *Z1, *Z2;   // KF_A0: Y is first updated, Y -= gamma_L*Z1 [; Y -= gamma_1*Z2]
-	int nz;                  // how many of Z1, Z2 are in use (l)
+	int nz;                  // how many of Z1, Z2 are in use (1 for l = 1, 0 for l = 2)
 	double *Xout;            // where psi is stored (ping-pong partner of X's role)
 	double *O, *O2;          // stencil output (O2: second copy, KF_RES only)
 	const double *lam, *Dxx, *Dyy, *Dzz, *Dxy;

@@ -350,9 +350,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	if (KIND != KF_SPMV && KIND != KF_RES && S->done) return;
 
 	const double cpsi = UPD ? (IS_A ? -S->beta : -S->alpha) : 0.;
-	// KF_A0 first applies the u0 update that closed the previous pass
-	// (solveLin_BICGStab.C:452, 458-459): u0 -= gamma_L*u_L [; u0 -= gamma_1*u_1],
-	// so the end-of-pass kernel neither reads u_1..u_L nor writes u0.
+	// l = 1: KF_A0 first applies the u0 update that closed the previous pass
+	// (solveLin_BICGStab.C:452): u0 -= gamma_1*u_1, so the end-of-pass kernel neither
+	// reads u_1 nor writes u0.  (nz = 0 for l = 2, whose end-of-pass kernel has u0 and
+	// u_1 in registers anyway and closes u0 itself.)
 	constexpr bool DEFER = (KIND == KF_A0);
 	const int nz = DEFER ? a.nz : 0;
 	const double dz1 = DEFER ? -S->gamma[S->L] : 0., dz2 = DEFER ? -S->gamma[1] : 0.;
@@ -827,12 +828,13 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 //   phi += alpha*u0 (deferred from the last BiCG step); phi += gamma1*r0;
 //   r0 -= gammap_L*r_L; then for jj = 1..L-1: phi += gammapp_jj*r_jj; r0 -= gammap_jj*r_jj;
 //   dots |r0|^2 and (r0, r~).
-// The u0 updates of these lines (u0 -= gamma_L*u_L; u0 -= gamma_jj*u_jj) are left to
-// the next pass's first stencil kernel, which reads u0 anyway.
+// l = 1: the u0 update of these lines (u0 -= gamma_1*u_1) is left to the next pass's
+// first stencil kernel, which reads u0 anyway.
 // l = 2 also carries the pointwise statements of the second BiCG step that no
 // stencil needs (:403 of jj = 0, :356-362 with ii = 0 and :392-394 with ii = 0 of
-// jj = 1): phi += alpha0*u0; u0 = r0 - beta*u0; r0 -= alpha*u1; then :403 of jj = 1.
-// v[0..L] = r0..rL, v[L+1] = u0, v[L+2] = r~, (l = 2) v[L+3] = u1;
+// jj = 1): phi += alpha0*u0; u0 = r0 - beta*u0; r0 -= alpha*u1; then :403 of jj = 1;
+// having u0 and u1 in registers for that, it also closes u0 (-= gamma_2*u2, -= gamma_1*u1).
+// v[0..L] = r0..rL, v[L+1] = u0, v[L+2] = r~, (l = 2) v[L+3] = u1, v[L+4] = u2;
 // w[0] = phi, w[1] = r0, (l = 2) w[2] = u0.
 template <int L, bool GEN>
 __global__ __launch_bounds__(NT) void k_final(const KryStream a)
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
-		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN], u1[L == 2 ? UN : 1];
+		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN], u1[L == 2 ? UN : 1], u2[L == 2 ? UN : 1];
 		// all loads first (reads past the end of a plane stay inside the allocation)
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			u0[i] = ld2s(a.v[L + 1] + p);
 			ph[i] = ld2s(a.w[0] + p);
 			rt[i] = ld2s(a.v[L + 2] + p);
-			if (L == 2) u1[L == 2 ? i : 0] = ld2s(a.v[L + 3] + p);
+			if (L == 2) { u1[L == 2 ? i : 0] = ld2s(a.v[L + 3] + p); u2[L == 2 ? i : 0] = ld2s(a.v[L + 4] + p); }
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
@@ -881,7 +883,10 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 					phv = axpy2(phv, u0[i], alpha0);                       // phi += alpha0*u0
 					u0[i] = axpy2(r[i][0], u0[i], nbeta);                  // u0 = r0' - beta*u0
 					r[i][0] = axpy2(r[i][0], u1[L == 2 ? i : 0], -alpha);  // r0'' = r0' - alpha*u1
-					st2s(a.w[2] + p, u0[i]);
+					// u0 -= gamma_2*u2 ; u0 -= gamma_1*u1 (:452, 458): u1 is here anyway, u2 costs one read
+					double2 un = axpy2(u0[i], u2[L == 2 ? i : 0], -g1[2 <= L ? 2 : L]);
+					un = axpy2(un, u1[L == 2 ? i : 0], -g1[1]);
+					st2s(a.w[2] + p, un);
 				}
 				phv = axpy2(phv, u0[i], alpha);
 				phv = axpy2(phv, r[i][0], g1[1]);

@@ -657,9 +657,8 @@ int fused_pass(kry_solver *h, int it)
 	CHK(stencil_step(h, KF_A0, [&](Slab &s) {
 		KryFused a = fused_base(h, s, PH_A);
 		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
-		a.nz = L;
-		if (L == 1) { a.Z1 = s.ub[1][p].p; a.O = s.ub[1][q].p; }
-		else { a.Z1 = s.ub[2][0].p; a.Z2 = s.ub[1][0].p; a.O = s.ub[1][1].p; }
+		if (L == 1) { a.nz = 1; a.Z1 = s.ub[1][p].p; a.O = s.ub[1][q].p; }
+		else { a.nz = 0; a.O = s.ub[1][1].p; }
 		return a;
 	}));
 	CHK(reduce_sums(h, PH_A));
@@ -727,6 +726,7 @@ int fused_pass(kry_solver *h, int it)
 			a.v[3] = s.ub[0][q].p;
 			a.v[4] = s.rt.p;
 			a.v[5] = s.ub[1][0].p;
+			a.v[6] = s.ub[2][0].p;
 			a.w[2] = s.ub[0][q].p;
 		}
 		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p;
