@@ -45,8 +45,8 @@ def kernel_words(L, var, offd):
     return {0: 6 + d,              # r0,u0,lam,rt -> u0,u1
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
             1: 6 + d,              # r1,u1,lam,rt -> u1,u2
-            4: 7 + d,              # r1,u2,lam,r0,u1 -> r1,r2
-            6: 4,                  # r2,r1,r0,u1 -> dots only (r2' and r0'' are recomputed by the last kernel)
+            4: 5 + d,              # r1,u2,lam -> r1,r2
+            6: 4,                  # r2,r1,r0,u1 -> three dots (r2' and r0'' are recomputed by the last kernel)
             7: 11}                 # phi,r0..r2,u0,u1,u2,rt -> phi,r0,u0
 
 

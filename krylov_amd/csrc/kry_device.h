@@ -76,7 +76,7 @@ enum KryPhase {
 	PH_A,         // sums[0] = (u[jj+1], r~)                     -> alpha
 	PH_B,         // sums[0] = (r[jj+1], r~)                     -> beta for the next jj
 	PH_BL1,       // l=1 last B: sums = (r0,r1), (r1,r1)          -> omega
-	PH_BL2,       // l=2 last B: sums = (r1,r1), (r0,r1), (r2,r1) -> sigma1, gammap1, tau12
-	PH_M2,        // l=2 MR:     sums = (r2,r2), (r0,r2)          -> gammas, omega
+	PH_BL2,       // l=2 last B: sums = (r1,r1), (r2,r1)          -> sigma1, tau12
+	PH_M2,        // l=2 MR:     sums = (r2,r2), (r0,r2), (r0,r1) -> gammap1, gammas, omega
 	PH_F          // sums = |r0|^2, (r0, r~)                      -> norm, convergence, next rho/beta
 };

@@ -14,7 +14,7 @@ enum KryFusedKind {
 	KF_A1,       // l=2, jj=1: u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)   (phi and u0 of this step: k_final)
 	KF_B0,       // l=2, jj=0: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 	KF_B0L,      // l=1:       r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
-	KF_B1L,      // l=2, jj=1: r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0 - alpha*u1, r1), (r2,r1)   (r0 is stored by k_final)
+	KF_B1L,      // l=2, jj=1: r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r2,r1)
 	KF_RES,      // r0 = r~ = rhs - A phi ; |r0|^2
 	KF_SPMV,     // out = A psi
 	KF_NKINDS
@@ -40,7 +40,7 @@ struct KryFused {
 	double *O, *O2;          // stencil output (O2: second copy, KF_RES only)
 	const double *lam, *Dxx, *Dyy, *Dzz, *Dxy;
 	const double *RT, *RHS;
-	double *phi, *E;         // KF_B1L: E = r0', Ea = u1 (read only: r0'' = r0' - alpha*u1 enters a dot)
+	double *phi, *E;         // (unused by the current kernels)
 	const double *Ea;
 	KryRed red;
 	int zlo, zhi;            // planes on which the stencil is evaluated

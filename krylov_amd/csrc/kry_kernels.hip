@@ -82,11 +82,11 @@ __device__ void kry_scalar_step(KryState *S, int phase)
 		break;
 	case PH_BL2:
 		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; break; }
-		S->sigma[1] = s[0];
-		S->gammap[1] = s[1] / S->sigma[1];
-		S->tau[1][2] = s[2] / S->sigma[1];        // :422
+		S->sigma[1] = s[0];                       // :427, jj = 1
+		S->tau[1][2] = s[1] / S->sigma[1];        // :422
 		break;
 	case PH_M2:
+		S->gammap[1] = s[2] / S->sigma[1];        // :428, jj = 1 (its dot rides in k_mgs2)
 		S->sigma[2] = s[0];
 		S->gammap[2] = s[1] / S->sigma[2];
 		S->omega = S->gamma[2] = S->gammap[2];
@@ -318,7 +318,7 @@ template <> struct KindTraits<KF_A0>   { static constexpr int ND = 1; static con
 template <> struct KindTraits<KF_A1>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
 template <> struct KindTraits<KF_B0>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
 template <> struct KindTraits<KF_B0L>  { static constexpr int ND = 2; static constexpr bool UPD = true;  };
-template <> struct KindTraits<KF_B1L>  { static constexpr int ND = 3; static constexpr bool UPD = true;  };
+template <> struct KindTraits<KF_B1L>  { static constexpr int ND = 2; static constexpr bool UPD = true;  };
 template <> struct KindTraits<KF_RES>  { static constexpr int ND = 1; static constexpr bool UPD = false; };
 template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static constexpr bool UPD = false; };
 
@@ -495,15 +495,8 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		if (GEN && cstore) a.Xout[pb + coff] = psi1(sx, sy, sz1, sz2);   // sx, sy, ... still hold plane z
 	};
-	// l = 2, last B kernel: r0'' = r0' - alpha*u1 (solveLin_BICGStab.C:392-394, ii = 0 of
-	// jj = 1) enters the dot (r0'', r1) here and is formed again, with the same two
-	// roundings, by the kernels that need it later (k_mgs2, k_final); it is not stored.
-	auto extras = [&](int z, int e, double2 &comp) {
-		if (KIND == KF_B1L) {
-			const long p = plane(z) + off[e];
-			comp = axpy2(ld2s(a.E + p), ld2s(a.Ea + p), cpsi);
-		}
-	};
+	// (pointwise companions of earlier versions now ride in the streaming kernels)
+	auto extras = [&](int, int, double2 &) {};
 
 	// ---- prologue: planes z0-1, z0 and the loads of z0+1 ----
 	issue(z0 - 1);
@@ -616,8 +609,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				add(acc[1], out.x * out.x, out.y * out.y);
 			} else if (KIND == KF_B1L) {
 				add(acc[0], pc[e].x * pc[e].x, pc[e].y * pc[e].y);
-				add(acc[1], comp.x * pc[e].x, comp.y * pc[e].y);
-				add(acc[2], out.x * pc[e].x, out.y * pc[e].y);
+				add(acc[1], out.x * pc[e].x, out.y * pc[e].y);
 			} else if (KIND == KF_RES) {
 				add(acc[0], out.x * out.x, out.y * out.y);
 			}
@@ -733,10 +725,8 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 			acc[ND > 1 ? 1 : 0] += wgt * (o * o);
 		} else if (KIND == KF_B1L) {
 			const double r1 = a.Xout[p];
-			const double r0 = axpy1(a.E[p], a.Ea[p], -a.S->alpha);   // r0'' as in k_fused<KF_B1L>
 			acc[0] += wgt * (r1 * r1);
-			acc[ND > 1 ? 1 : 0] += wgt * (r0 * r1);
-			acc[ND > 2 ? 2 : 0] += wgt * (o * r1);
+			acc[ND > 1 ? 1 : 0] += wgt * (o * r1);
 		}
 	}
 	KryRed r = a.red;
@@ -748,7 +738,8 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 // ---------------------------------------------------------------------------
 
 // l = 2 modified Gram-Schmidt step: r2' = r2 - tau12*r1 ; (r2',r2'), (r0'',r2')
-// (solveLin_BICGStab.C:420-428, jj = 2) with r0'' = r0' - alpha*u1 (:392-394).
+// (solveLin_BICGStab.C:420-428, jj = 2) with r0'' = r0' - alpha*u1 (:392-394), and the
+// dot (r0'', r1) of jj = 1 (:428), whose operands are all here.
 // Neither r2' nor r0'' is written back: k_final recomputes both with the same two
 // roundings, and r2 is overwritten by the next pass before any other read.
 // v[0] = r0', v[1] = r1, v[2] = r2, v[3] = u1.
@@ -779,7 +770,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 	constexpr int UN = SEG2 / NT;
 	const double ntau = -S->tau[1][2];
 	const double nalpha = -S->alpha;
-	double acc[2] = {0., 0.};
+	double acc[3] = {0., 0., 0.};
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
 	if (GEN) {
@@ -813,15 +804,17 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 						const double w0 = wxy[GEN ? i : 0][0] * wz, w1 = wxy[GEN ? i : 0][1] * wz;
 						acc[0] += w0 * (r2[i].x * r2[i].x); acc[0] += w1 * (r2[i].y * r2[i].y);
 						acc[1] += w0 * (r0[i].x * r2[i].x); acc[1] += w1 * (r0[i].y * r2[i].y);
+						acc[2] += w0 * (r0[i].x * r1[i].x); acc[2] += w1 * (r0[i].y * r1[i].y);
 					}
 				} else if (cnt) {
 					acc[0] += r2[i].x * r2[i].x; acc[0] += r2[i].y * r2[i].y;
 					acc[1] += r0[i].x * r2[i].x; acc[1] += r0[i].y * r2[i].y;
+					acc[2] += r0[i].x * r1[i].x; acc[2] += r0[i].y * r1[i].y;
 				}
 			}
 		}
 	}
-	reduce_and_finalize<2>(acc, a.red);
+	reduce_and_finalize<3>(acc, a.red);
 }
 
 // End of an outer pass (solveLin_BICGStab.C:403, 450-464):

@@ -689,16 +689,15 @@ int fused_pass(kry_solver *h, int it)
 			return a;
 		}));
 		CHK(reduce_sums(h, PH_A));
-		// --- jj = 1, B (last): r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r0 - alpha*u1, r1), (r2,r1)
+		// --- jj = 1, B (last): r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r2,r1)
 		CHK(stencil_step(h, KF_B1L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL2);
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
 			a.O = s.rb[2][0].p;
-			a.E = s.rb[0][q].p; a.Ea = s.ub[1][0].p;
 			return a;
 		}));
 		CHK(reduce_sums(h, PH_BL2));
-		// --- MR: r2 -= tau12*r1 ; (r2,r2), (r0,r2)
+		// --- MR: r2 -= tau12*r1 ; (r2,r2), (r0,r2), and (r0,r1) of jj = 1
 		CHK(for_slabs([&](Slab &s, int) -> int {
 			int nbx, nby;
 			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby, 4);

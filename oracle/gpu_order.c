@@ -423,8 +423,9 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 			return fused_gen_sum(c, a, b);
 		case ORC_SITE_ALPHA:
 		case ORC_SITE_TAU:       return fused_gen_sum(c, a, b);
-		case ORC_SITE_SIGMA:
-		case ORC_SITE_GAMMAP:    return jj == 1 ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
+		case ORC_SITE_SIGMA:     return jj == 1 ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
+		case ORC_SITE_GAMMAP:    /* l = 2: the dot (r0, r1) rides in k_mgs2 */
+			return (jj == 1 && c->L == 1) ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
 		case ORC_SITE_NORM:      return sqrt(stream_gen_sum(c, a, b, 1, 1));
 		}
 		return orc_dot(c, a, b);
@@ -438,8 +439,9 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 		return fused_sum(c, a, b);                                        /* B kernel of jj-1 */
 	case ORC_SITE_ALPHA:     return fused_sum(c, a, b);                   /* A kernels */
 	case ORC_SITE_TAU:       return fused_sum(c, a, b);                   /* last B kernel */
-	case ORC_SITE_SIGMA:
-	case ORC_SITE_GAMMAP:    return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);   /* k_mgs2 */
+	case ORC_SITE_SIGMA:     return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);   /* k_mgs2 */
+	case ORC_SITE_GAMMAP:    /* l = 2: the dot (r0, r1) rides in k_mgs2 */
+		return (jj == 1 && c->L == 1) ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);
 	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b, 1));
 	}
 	return orc_dot(c, a, b);
