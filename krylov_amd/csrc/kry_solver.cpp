@@ -113,7 +113,7 @@ struct kry_solver {
 	KryOp op;
 	int ty = 8, zc = 16;
 	bool zc_fixed = false;     // KRY_ZC given: no automatic choice
-	int stream_blocks = 32768; // target grid size of the streaming kernels
+	int stream_blocks = 65536; // target grid size of the streaming kernels
 	std::vector<Slab> slabs;
 	KryComm comm;
 	// run state
