@@ -32,6 +32,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from krylov_amd import gloo_transport
     allreduce, halo = gloo_transport.make(rank, world)
+    use_rccl = os.environ.get("KRY_TEST_RCCL") == "1"      # one GPU per process, RCCL as the transport
+    dev = rank if use_rccl else 0
 
     import slab_reference as SR
     from test_gpu_multiproc import make_problem
@@ -40,14 +42,19 @@ def main():
     if nproc is None:
         loc = SR.split_problem(P, p, world, rank)
         solver = capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, nslabs=world,
-                             slab_begin=rank, slab_count=1, devices=(0,))
+                             slab_begin=rank, slab_count=1, devices=(dev,))
     else:
         coord = (rank // (nproc[1] * nproc[2]), (rank // nproc[2]) % nproc[1], rank % nproc[2])
         loc = SR.split_brick(P, p, nproc, coord)
-        solver = capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, devices=(0,),
+        solver = capi.Solver(loc.mx, loc.delx, loc.bc, L=L, eps=eps, max_outer=max_outer, flags=flags, devices=(dev,),
                              nproc=nproc, coord=coord)
     with solver as s:
-        s.comm_init_callbacks(rank, world, allreduce, halo)
+        if use_rccl:
+            uid = [capi.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            s.comm_init(uid[0], rank, world)
+        else:
+            s.comm_init_callbacks(rank, world, allreduce, halo)
         phi = loc.phi.copy()
         if loc.var_coef:
             st = s.solve_var(phi, loc.rhs, loc.lam, loc.Dxx, loc.Dyy, loc.Dzz, loc.Dxy, loc.use_offdiag)

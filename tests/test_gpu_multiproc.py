@@ -140,3 +140,30 @@ def test_rccl_transport_selftest():
     send/receive to self, data verified inside the library."""
     from krylov_amd import capi
     assert capi.comm_selftest(0) == 0
+
+
+def _gpu_count():
+    import ctypes as C
+    from krylov_amd import capi
+    n = C.c_int(0)
+    L = capi.lib()
+    L.hipGetDeviceCount.argtypes = [C.POINTER(C.c_int)]
+    return n.value if L.hipGetDeviceCount(C.byref(n)) == 0 else 0
+
+
+@gpu
+@pytest.mark.parametrize("kind,L,nproc", [("var", 2, None), ("mixed", 2, None), ("var", 2, (1, 2, 1))])
+def test_rccl_transport_between_gpus(tmp_path, monkeypatch, kind, L, nproc):
+    """One process per GPU with RCCL as the transport (the layout of `bench.py --gpus N`).
+    Needs at least two GPUs; the per-rank sums are all-reduced by RCCL, whose summation
+    order is its own, so the comparison is to rounding noise, not bit for bit."""
+    from krylov_amd import capi
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    monkeypatch.setenv("KRY_TEST_RCCL", "1")
+    p = make_problem(kind)
+    one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3)
+    parts = run_ranks(2, kind, L, 3, 1e-30, str(tmp_path), nproc)
+    for d in parts:
+        assert int(d["iters"]) == 3
+        assert np.max(np.abs(d["hist"] - one["history"])) <= 1e-10 * one["norm_rhs"]
