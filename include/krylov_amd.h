@@ -145,6 +145,25 @@ int kry_comm_init_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb
 int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allreduce_cb allreduce, kry_halo_cb halo,
                                  void *ctx);
 
+/* All-reduce of the dot products through device mailboxes instead of the transport's
+ * all-reduce (the reference: MPI_Allreduce, BICGStab3D/Krylov.C:149-150, 239-240), for
+ * processes whose GPUs can address each other (one node, xGMI or the same device).
+ * The block that finishes a reduction kernel stores its sums into every rank's mailbox
+ * and adds the ranks' contributions in rank order itself: no extra kernel launch per
+ * dot product, and the same bits on every rank.  The transport set with kry_comm_init*
+ * stays in use for the ghost planes.
+ *   kry_mail_export:  creates this rank's mailbox, writes its HIP IPC handle
+ *                     (KRY_MAIL_HANDLE_BYTES bytes) to `handle`;
+ *   kry_mail_connect: `handles` = the nranks handles in rank order (all-gathered by the
+ *                     caller); maps the peers' mailboxes and switches the path on;
+ *   kry_mail_enable:  switches it off / on again (between solves).
+ * A rank that waits longer than KRY_MAIL_TIMEOUT_MS (default 30000) for a peer stops
+ * the solve with KRY_ERR_COMM.  At most 64 ranks. */
+#define KRY_MAIL_HANDLE_BYTES 64
+int kry_mail_export(kry_handle h, void *handle);
+int kry_mail_connect(kry_handle h, int rank, int nranks, const void *handles);
+int kry_mail_enable(kry_handle h, int on);
+
 /* Replaces BICGStab::solve(bounds, phi, rhs, lambda, D_xx, D_yy, D_zz, debug)
  * (BICGStab3D/solveLin_BICGStab.C:200-215).  phi: initial guess in, solution
  * out.  Returns a status instead of calling exit(). */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkrylov_amd.so")
 
 KRY_MAX_SLABS = 16
 KRY_UID_BYTES = 128
+KRY_MAIL_HANDLE_BYTES = 64
 KRY_FORCE_GENERIC = 1
 
 STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reached",
@@ -22,7 +23,7 @@ STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reache
 # every symbol include/krylov_amd.h declares
 SYMBOLS = [
     "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks", "kry_device_check",
-    "kry_comm_selftest", "kry_solve_const",
+    "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
     "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
@@ -102,6 +103,12 @@ def lib():
     L.kry_comm_selftest.argtypes = [ci]
     L.kry_comm_init_callbacks.restype = ci
     L.kry_comm_init_callbacks.argtypes = [vp, ci, ci, ALLREDUCE_CB, HALO_CB, vp]
+    L.kry_mail_export.restype = ci
+    L.kry_mail_export.argtypes = [vp, vp]
+    L.kry_mail_connect.restype = ci
+    L.kry_mail_connect.argtypes = [vp, ci, ci, vp]
+    L.kry_mail_enable.restype = ci
+    L.kry_mail_enable.argtypes = [vp, ci]
     L.kry_solve_const.restype = ci
     L.kry_solve_const.argtypes = [vp, _dp, _dp, _dp, cd, cd, cd, ci]
     L.kry_solve_var.restype = ci
@@ -234,6 +241,22 @@ class Solver:
         self._cbs = (ALLREDUCE_CB(ar), HALO_CB(hl))      # keep alive
         _check(lib().kry_comm_init_callbacks(self._h, rank, nranks, self._cbs[0], self._cbs[1], None),
                "kry_comm_init_callbacks")
+
+    def mail_export(self):
+        """This rank's mailbox handle (bytes) for the device-side all-reduce."""
+        buf = C.create_string_buffer(KRY_MAIL_HANDLE_BYTES)
+        _check(lib().kry_mail_export(self._h, buf), "kry_mail_export")
+        return buf.raw
+
+    def mail_connect(self, rank, nranks, handles):
+        """`handles`: the ranks' mail_export() results in rank order."""
+        blob = b"".join(bytes(x) for x in handles)
+        assert len(blob) == nranks * KRY_MAIL_HANDLE_BYTES
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(lib().kry_mail_connect(self._h, rank, nranks, buf), "kry_mail_connect")
+
+    def mail_enable(self, on):
+        _check(lib().kry_mail_enable(self._h, int(bool(on))), "kry_mail_enable")
 
     def solve_const(self, phi, rhs, lam, Dc, debug=0):
         return _check(lib().kry_solve_const(self._h, phi, rhs, lam, Dc[0], Dc[1], Dc[2], debug),

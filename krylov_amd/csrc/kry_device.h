@@ -69,6 +69,24 @@ struct KryState {
 	double hist[KRY_HIST_CAP];
 };
 
+// Mailbox all-reduce between the processes of a split domain (one GPU each).
+// Every rank owns a mailbox in uncached device memory that all peers have mapped
+// (HIP IPC).  The block that finishes a grid reduction stores its sums into slot
+// [parity][own rank] of every rank's mailbox, followed by the sequence number of
+// the reduction, waits until all slots of its own mailbox carry that number and
+// adds them in rank order: every rank obtains the same bits, with no further
+// kernel launch.  Two parities suffice, since a rank can be at most one reduction
+// ahead of a peer (it needs the peer's message to finish the current one).
+#define KRY_MAIL_MAX 64       // ranks
+#define KRY_MAIL_SLOT 16      // doubles per message: KRY_NSUMS values, sequence word, padding
+struct KryMail {
+	int rank, nranks;
+	long long timeout;        // wall_clock64 ticks a rank waits for a peer before it gives up
+	double *box;              // own mailbox: KRY_MAIL_SLOT header doubles (word 0: sequence counter),
+	                          // then [2][nranks][KRY_MAIL_SLOT]
+	double *peer[KRY_MAIL_MAX];   // every rank's mailbox as mapped into this process (peer[rank] == box)
+};
+
 // Phases of the scalar recurrences (which dots just became available).
 enum KryPhase {
 	PH_NONE = 0,

@@ -157,6 +157,68 @@ __device__ inline double pub_load(const double *p)
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Tail of a grid reduction when the domain is split over processes: this rank's
+// sums (the rows of `red`, still to be added) go to every rank's mailbox, the
+// ranks' contributions are added in rank order.  Run by the whole last block;
+// lane r of the block talks to rank r.
+template <int ND>
+__device__ inline void mail_allreduce(double (*red)[ND], const KryRed &r)
+{
+	static_assert(ND <= KRY_NSUMS, "message slot too small");
+	const KryMail *m = r.mail;
+	const int tid = threadIdx.x, n = m->nranks, me = m->rank;
+	__shared__ double mine[KRY_NSUMS];
+	__shared__ int failed;
+	unsigned long long *seqp = reinterpret_cast<unsigned long long *>(m->box);
+	if (tid < ND) {
+		double v = red[0][tid];
+#pragma unroll
+		for (int i = 1; i < NW; ++i) v += red[i][tid];
+		mine[tid] = v;
+	}
+	if (tid == 0) failed = 0;
+	__syncthreads();
+	const unsigned long long seq = *seqp + 1ull;
+	const long slot0 = KRY_MAIL_SLOT + (long)(seq & 1ull) * n * KRY_MAIL_SLOT;
+	for (int p = tid; p < n; p += NT) {
+		double *dst = m->peer[p] + slot0 + (long)me * KRY_MAIL_SLOT;
+#pragma unroll
+		for (int k = 0; k < ND; ++k) __hip_atomic_store(dst + k, mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + KRY_NSUMS), seq, __ATOMIC_RELEASE,
+		                   __HIP_MEMORY_SCOPE_SYSTEM);
+		const unsigned long long *flag =
+		    reinterpret_cast<const unsigned long long *>(m->box + slot0 + (long)p * KRY_MAIL_SLOT + KRY_NSUMS);
+		const long long t0 = wall_clock64();
+		unsigned spins = 0;
+		while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+			__builtin_amdgcn_s_sleep(4);
+			if ((++spins & 255u) == 0u && wall_clock64() - t0 > m->timeout) {
+				failed = 1;          // the peer never arrived: give up, every later kernel exits at once
+				break;
+			}
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		const double *src = m->box + slot0;
+#pragma unroll
+		for (int k = 0; k < ND; ++k) {
+			double v = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			for (int p = 1; p < n; ++p)
+				v += __hip_atomic_load(src + (long)p * KRY_MAIL_SLOT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			r.S->sums[k] = failed ? __builtin_nan("") : v;
+		}
+		*seqp = seq;
+		__hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (failed) {
+			r.S->status = -3;    // KRY_ERR_COMM
+			r.S->done = 1;
+		} else if (r.S->local_scalars && r.phase != PH_NONE) {
+			kry_scalar_step(r.S, r.phase);
+		}
+	}
+}
+
 template <int ND>
 __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, int blk_off = 0)
 {
@@ -208,6 +270,10 @@ __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, i
 		if (lane == 0) red[w][k] = v;
 	}
 	__syncthreads();
+	if (r.mail) {
+		mail_allreduce<ND>(red, r);
+		return;
+	}
 	if (tid == 0) {
 #pragma unroll
 		for (int k = 0; k < ND; ++k) {

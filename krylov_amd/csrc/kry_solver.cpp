@@ -84,6 +84,11 @@ struct Slab {
 	size_t stage_cap = 0;
 	double *xy_buf = nullptr;  // packed x / y faces of the Cartesian split: 3 planes out, 3 planes in
 	size_t xy_plane = 0;       // doubles per packed plane slot
+	// mailbox all-reduce between processes (kry_mail_export / kry_mail_connect)
+	double *mail_box = nullptr;        // own mailbox, uncached device memory, exported over HIP IPC
+	KryMail *mail_dev = nullptr;       // its description for the kernels
+	std::vector<void *> mail_mapped;   // peers' mailboxes as opened here
+	bool mail_on = false;
 	std::vector<Field *> all;
 };
 
@@ -280,7 +285,7 @@ int reduce_sums(kry_solver *h, int phase)
 {
 	const int ns = (int)h->slabs.size();
 	const bool remote = h->comm.active();
-	if (ns == 1 && !remote) return 0;
+	if (ns == 1 && (!remote || h->slabs[0].mail_on)) return 0;   // the kernel's last block did it all
 	Slab &s0 = h->slabs[0];
 	// The total is formed in a buffer of its own (the first slab's `gather` tail):
 	// S->sums of a slab is rewritten by that slab's next reducing kernel, which
@@ -452,6 +457,13 @@ int exchange_halo_end(kry_solver *h)
 	return 0;
 }
 
+// 1: the kernel that finishes a reduction also advances the recurrences (one slab in
+// this process, and either no other process or the mailbox all-reduce between them)
+int local_scalars(const kry_solver *h)
+{
+	return (h->slabs.size() == 1 && (!h->comm.active() || h->slabs[0].mail_on)) ? 1 : 0;
+}
+
 KryRed make_red(Slab &s, int nblk, int phase)
 {
 	KryRed r;
@@ -460,6 +472,7 @@ KryRed make_red(Slab &s, int nblk, int phase)
 	r.S = s.S;
 	r.nblk = nblk;
 	r.phase = phase;
+	r.mail = s.mail_on ? s.mail_dev : nullptr;
 	return r;
 }
 
@@ -1034,7 +1047,7 @@ int prologue(kry_solver *h)
 		init.norm_rhs = h->norm_rhs;
 		init.max_outer = h->d.max_outer;
 		init.L = h->L;
-		init.local_scalars = (h->slabs.size() == 1 && !h->comm.active()) ? 1 : 0;
+		init.local_scalars = local_scalars(h);
 		init.norm_init = std::sqrt(ss);
 		init.norm = 1.e99;
 		if (init.norm_init < h->d.eps * h->norm_rhs) {
@@ -1067,7 +1080,7 @@ int prologue(kry_solver *h)
 			init.norm_rhs = h->norm_rhs;
 			init.max_outer = h->d.max_outer;
 			init.L = h->L;
-			init.local_scalars = (h->slabs.size() == 1 && !h->comm.active()) ? 1 : 0;
+			init.local_scalars = local_scalars(h);
 			memcpy(s.Sh, &init, offsetof(KryState, hist));
 			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
 			HIPCHK(hipStreamSynchronize(s.st));
@@ -1471,6 +1484,9 @@ void kry_destroy(kry_handle h)
 		if (s.gather) hipFree(s.gather);
 		if (s.stage) hipFree(s.stage);
 		if (s.xy_buf) hipFree(s.xy_buf);
+		for (void *m : s.mail_mapped) hipIpcCloseMemHandle(m);
+		if (s.mail_dev) hipFree(s.mail_dev);
+		if (s.mail_box) hipFree(s.mail_box);
 		if (s.ev) hipEventDestroy(s.ev);
 		if (s.ev_in) hipEventDestroy(s.ev_in);
 		if (s.ev_edge) hipEventDestroy(s.ev_edge);
@@ -1552,6 +1568,83 @@ int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allredu
 	int st = h->comm.init_host_callbacks(rank, nranks, allreduce, halo, ctx);
 	if (st < 0) set_err("%s", KryComm::last_error());
 	return st;
+}
+
+static size_t mail_bytes(int nranks) { return sizeof(double) * KRY_MAIL_SLOT * (1 + 2 * (size_t)nranks); }
+
+int kry_mail_export(kry_handle h, void *handle)
+{
+	if (!h || !handle) { set_err("null argument"); return KRY_ERR_ARG; }
+	static_assert(sizeof(hipIpcMemHandle_t) == KRY_MAIL_HANDLE_BYTES, "IPC handle size");
+	if (h->d.slab_count != 1) { set_err("kry_mail_export: one sub-domain per process"); return KRY_ERR_ARG; }
+	if (h->n_ranks() > KRY_MAIL_MAX) { set_err("kry_mail_export: at most %d ranks", KRY_MAIL_MAX); return KRY_ERR_ARG; }
+	Slab &s = h->slabs[0];
+	HIPCHK(hipSetDevice(s.device));
+	if (!s.mail_box) {
+		// uncached, so that what a peer GPU stores is seen by a kernel already running here
+		HIPCHK(hipExtMallocWithFlags((void **)&s.mail_box, mail_bytes(KRY_MAIL_MAX), hipDeviceMallocUncached));
+		HIPCHK(hipMemset(s.mail_box, 0, mail_bytes(KRY_MAIL_MAX)));
+	}
+	hipIpcMemHandle_t hd;
+	HIPCHK(hipIpcGetMemHandle(&hd, s.mail_box));
+	memcpy(handle, &hd, sizeof hd);
+	return KRY_OK;
+}
+
+int kry_mail_connect(kry_handle h, int rank, int nranks, const void *handles)
+{
+	if (!h || !handles) { set_err("null argument"); return KRY_ERR_ARG; }
+	if (h->d.slab_count != 1 || h->n_ranks() != nranks || h->my_rank() != rank || nranks > KRY_MAIL_MAX) {
+		set_err("kry_mail_connect: rank r must own exactly sub-domain r, at most %d ranks (rank=%d/%d, sub-domain %d of %d)",
+		        KRY_MAIL_MAX, rank, nranks, h->my_rank(), h->n_ranks());
+		return KRY_ERR_ARG;
+	}
+	Slab &s = h->slabs[0];
+	if (!s.mail_box) { set_err("kry_mail_connect: call kry_mail_export first"); return KRY_ERR_STATE; }
+	if (s.mail_dev) { set_err("kry_mail_connect: already connected"); return KRY_ERR_STATE; }
+	HIPCHK(hipSetDevice(s.device));
+	KryMail m;
+	memset(&m, 0, sizeof m);
+	m.rank = rank;
+	m.nranks = nranks;
+	int khz = 0;
+	if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s.device) != hipSuccess || khz <= 0) khz = 100000;
+	const char *e = getenv("KRY_MAIL_TIMEOUT_MS");
+	const long ms = e ? std::max(1L, atol(e)) : 30000L;
+	m.timeout = (long long)khz * ms;
+	m.box = s.mail_box;
+	for (int r = 0; r < nranks; ++r) {
+		if (r == rank) { m.peer[r] = s.mail_box; continue; }
+		hipIpcMemHandle_t hd;
+		memcpy(&hd, (const char *)handles + (size_t)r * sizeof hd, sizeof hd);
+		void *p = nullptr;
+		hipError_t err = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+		if (err != hipSuccess) {
+			set_err("kry_mail_connect: cannot map the mailbox of rank %d: %s", r, hipGetErrorString(err));
+			for (void *q : s.mail_mapped) hipIpcCloseMemHandle(q);
+			s.mail_mapped.clear();
+			return KRY_ERR_COMM;
+		}
+		s.mail_mapped.push_back(p);
+		m.peer[r] = (double *)p;
+	}
+	HIPCHK(hipMalloc((void **)&s.mail_dev, sizeof m));
+	HIPCHK(hipMemcpy(s.mail_dev, &m, sizeof m, hipMemcpyHostToDevice));
+	return kry_mail_enable(h, 1);
+}
+
+int kry_mail_enable(kry_handle h, int on)
+{
+	if (!h) { set_err("null argument"); return KRY_ERR_ARG; }
+	Slab &s = h->slabs[0];
+	if (on && !s.mail_dev) { set_err("kry_mail_enable: not connected"); return KRY_ERR_STATE; }
+	HIPCHK(hipSetDevice(s.device));
+	HIPCHK(hipStreamSynchronize(s.st));
+	drop_graph(h);
+	s.mail_on = on != 0;
+	const int ls = local_scalars(h);
+	HIPCHK(hipMemcpy(&s.S->local_scalars, &ls, sizeof ls, hipMemcpyHostToDevice));
+	return KRY_OK;
 }
 
 int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda, double Dxx,

@@ -55,6 +55,10 @@ def main():
             s.comm_init(uid[0], rank, world)
         else:
             s.comm_init_callbacks(rank, world, allreduce, halo)
+        if os.environ.get("KRY_TEST_MAIL") == "1":         # dot products all-reduced through device mailboxes
+            handles = [None] * world
+            dist.all_gather_object(handles, s.mail_export())
+            s.mail_connect(rank, world, handles)
         phi = loc.phi.copy()
         if loc.var_coef:
             st = s.solve_var(phi, loc.rhs, loc.lam, loc.Dxx, loc.Dyy, loc.Dzz, loc.Dxy, loc.use_offdiag)

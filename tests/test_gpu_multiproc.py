@@ -123,6 +123,27 @@ def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, 
 
 
 @gpu
+@pytest.mark.parametrize("world,kind,L,nproc", [(2, "var", 2, None), (4, "var", 2, None), (2, "const", 1, None),
+                                                (4, "mixed", 2, None), (2, "mixed_generic", 2, None),
+                                                (4, "var", 2, (1, 2, 2)), (4, "var", 1, (2, 2, 1))])
+def test_mailbox_allreduce_reproduces_the_transport_allreduce(tmp_path, monkeypatch, world, kind, L, nproc):
+    """The dot products all-reduced by the reduction kernels themselves, through mailboxes the
+    processes map from each other (HIP IPC; here all on one device), against the same run with the
+    transport's all-reduce: both add the ranks' sums in rank order, so the histories are equal bit
+    for bit."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    monkeypatch.setenv("KRY_MAIL_TIMEOUT_MS", "20000")
+    plain = run_ranks(world, kind, L, 4, 1e-30, str(tmp_path / "a"), nproc)
+    monkeypatch.setenv("KRY_TEST_MAIL", "1")
+    mail = run_ranks(world, kind, L, 4, 1e-30, str(tmp_path / "b"), nproc)
+    for a, b in zip(plain, mail):
+        assert int(b["iters"]) == 4 and int(b["status"]) == int(a["status"])
+        assert np.array_equal(a["hist"], b["hist"])
+        assert np.array_equal(a["phi"], b["phi"])
+
+
+@gpu
 def test_processes_full_solve(tmp_path):
     from krylov_amd import capi
     p = make_problem("var")
