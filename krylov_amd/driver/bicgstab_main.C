@@ -13,6 +13,11 @@
 // each (KRY_DEVICES lists the devices, default all on 0): 2 x 2 x 2 for P = 8 as the
 // reference hard-codes (BICGStab3D/main.C:145-150), P z slabs otherwise, or
 // `--nproc NX NY NZ`.
+//
+// Built with -D WITH_HDF5 (bicgstab_h5) it also writes and reads field files in the
+// format of the reference's Hdf5Stream classes (BICGStab3D/Hdf5File_cbase.H:18-144):
+// `-o FILE` stores phi, phi_ana and rhs after the solve, `--restart FILE` takes the
+// initial guess from the phi of such a file.  Under MPI every process uses FILE.<rank>.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -25,6 +30,9 @@
 #include "../compat/LinSolver3D.hpp"
 #include "../compat/grid_manager.H"
 #include "../compat/solveLin_BICGStab.H"
+#ifdef WITH_HDF5
+#include "../compat/Hdf5File_cbase.H"
+#endif
 
 using namespace std;
 
@@ -50,6 +58,7 @@ struct Options {
 	bool quiet = false;
 	unsigned seed = 12345;
 	int nproc[3] = {0, 0, 0};   // -D parallel: process grid (0 = choose from the process count)
+	string output, restart;     // field files (WITH_HDF5)
 };
 
 void usage(const char *argv0)
@@ -68,6 +77,10 @@ void usage(const char *argv0)
 	cout << "    -s   --seed SEED              Seed for --randomize" << endl;
 	cout << "         --stats                  Print one CSV row instead of the report" << endl;
 	cout << "    -q   --quiet                  No per-iteration output" << endl;
+#ifdef WITH_HDF5
+	cout << "    -o   --output FILE            Write phi, phi_ana and rhs to an HDF5 field file" << endl;
+	cout << "         --restart FILE           Initial guess: phi of an HDF5 field file" << endl;
+#endif
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -91,6 +104,10 @@ bool parse(int argc, char **argv, Options &o)
 		else if (a == "--nproc") { for (int d = 0; d < 3; ++d) o.nproc[d] = atoi(need("Process grid")); }
 		else if (a == "--stats") o.stats = true;
 		else if (a == "-q" || a == "--quiet") o.quiet = true;
+#ifdef WITH_HDF5
+		else if (a == "-o" || a == "--output") o.output = need("Output file");
+		else if (a == "--restart") o.restart = need("Restart file");
+#endif
 		else if (!a.empty() && a[0] != '-') o.mx = atoi(a.c_str());
 		else { cerr << "Illegal argument: " << a << endl; return false; }
 	}
@@ -213,6 +230,20 @@ int main(int argc, char *argv[])
 				}
 			}
 
+#ifdef WITH_HDF5
+	const string suffix = [&] {
+#ifdef parallel
+		return "." + to_string(rank);
+#else
+		return string();
+#endif
+	}();
+	if (!opt.restart.empty()) {
+		Hdf5iStream in(opt.restart + suffix, talk ? 0 : 1);
+		in.Read3DMatrix("phi", phi);
+	}
+#endif
+
 	if (talk) cout << " bauen " << endl;
 	Linsolver3D *lin_solver = new BICGStab();
 	NumArray<int> pars(1);
@@ -252,6 +283,26 @@ int main(int argc, char *argv[])
 	const double l2err = sqrt(error / num);
 
 	BICGStab *bs = static_cast<BICGStab *>(lin_solver);
+#ifdef WITH_HDF5
+	if (!opt.output.empty()) {
+		double xb[3], dx[3];
+		for (int d = 0; d < 3; ++d) {
+			dx[d] = PosGrid.get_delx(d);
+			xb[d] = PosGrid.get_Pos(d, -1);       // position of the first stored element (the ghost layer)
+		}
+		Hdf5Stream out(opt.output + suffix, 3, rank);
+		out.AddGlobalAttr("test", opt.test);
+		out.AddGlobalAttr("mx", opt.mx);
+		out.AddGlobalAttr("lvalue", opt.L);
+		out.AddGlobalAttr("tolerance", opt.tol);
+		out.AddGlobalAttr("iterations", bs->iterations());
+		out.AddGlobalAttr("l2_error", l2err);
+		out.Write3DMatrix("phi", phi, xb, dx);
+		out.Write3DMatrix("phi_ana", phi_ana, xb, dx);
+		out.Write3DMatrix("rhs", rhs, xb, dx);
+		out.close();
+	}
+#endif
 	if (rank != 0) {
 		// only the first process reports
 	} else if (opt.stats) {

@@ -144,3 +144,38 @@ def test_opencl_solver_style_class():
     assert int(out[0]) == ref["iters"] and int(out[3]) == ref["iters"]
     assert np.array_equal(phi, ref["phi"])
     assert 0 <= out[1] <= out[2] and out[4] > 0.
+
+
+DRIVER_H5 = os.path.join(ROOT, "krylov_amd", "driver", "bicgstab_h5")
+
+
+def test_driver_writes_field_file_and_restarts_from_it(tmp_path):
+    """`bicgstab_h5 -o FILE` stores the solution as an HDF5 field file in the reference's
+    layout (BICGStab3D/Hdf5File_cbase.C:629-699); started again with `--restart FILE` the
+    solver finds its initial residual below the tolerance and makes no pass."""
+    import shutil
+    if not os.path.exists(DRIVER_H5):
+        pytest.skip("built without HDF5")
+    path = str(tmp_path / "fields.h5")
+    first = subprocess.run([DRIVER_H5, "-n", "32", "-t", "2", "-q", "-o", path], capture_output=True, text=True,
+                           timeout=120)
+    assert first.returncode == 0, first.stdout + first.stderr
+    its = int(re.search(r"Iterations\s*:\s*(\d+)", first.stdout).group(1))
+    err = float(re.search(r"l2 error for 32 is (\S+)", first.stdout).group(1))
+    assert its > 3 and os.path.getsize(path) > 3 * 35 ** 3 * 8
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        head = subprocess.run([h5dump, "-H", path], capture_output=True, text=True, check=True).stdout
+        for ds in ("phi", "phi_ana", "rhs"):
+            assert re.search(r'DATASET "%s" \{\s*DATATYPE\s+H5T_IEEE_F64LE\s+DATASPACE\s+SIMPLE \{ \( 35, 35, 35 \)' % ds,
+                             head)
+        attr = subprocess.run([h5dump, "-a", "/Data/iterations", "-a", "/Data/phi/origin", path], capture_output=True,
+                              text=True, check=True).stdout
+        vals = re.findall(r"\(0\): (.*)", attr)
+        assert int(vals[0]) == its
+        assert [float(v) for v in vals[1].split(",")] == [-1. / 32] * 3      # first stored element: the ghost layer
+    again = subprocess.run([DRIVER_H5, "-n", "32", "-t", "2", "-q", "--restart", path], capture_output=True, text=True,
+                           timeout=120)
+    assert again.returncode == 0, again.stdout + again.stderr
+    assert int(re.search(r"Iterations\s*:\s*(\d+)", again.stdout).group(1)) == 0
+    assert float(re.search(r"l2 error for 32 is (\S+)", again.stdout).group(1)) == err

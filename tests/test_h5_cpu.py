@@ -1,0 +1,122 @@
+"""Field files (HDF5) of the adaptor layer: layout on disk as the reference writes it
+(BICGStab3D/Hdf5File_cbase.C:48-86, 386-423, 629-699, 1163-1236, 1748-1835, 1908-2060) and
+the way back through the reader class (:1085-1130, 1686-1744).  The reference holds no
+sample file, so the layout is checked against its source as cited (parity unpinned beyond
+that); h5dump of the HDF5 installation lists the structure."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "krylov_amd", "libkrylov_compat_hdf5.so")
+H5DUMP = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="built without HDF5")
+
+dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i3 = C.c_int * 3
+d3 = C.c_double * 3
+
+
+def lib():
+    L = C.CDLL(LIB)
+    L.compat_h5_write.restype = C.c_int
+    L.compat_h5_write.argtypes = [C.c_char_p, i3, C.c_int, dp, dp, d3, d3, C.c_int, C.c_double]
+    L.compat_h5_read.restype = C.c_int
+    L.compat_h5_read.argtypes = [C.c_char_p, i3, C.c_int, dp, dp, fp, d3, d3, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_double), i3, i3, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                 C.c_char_p, C.c_int, C.POINTER(C.c_float)]
+    return L
+
+
+MX, RIM = (6, 4, 5), 1          # unequal extents, so that a swapped axis shows
+SHAPE = tuple(MX[d] + 1 + 2 * RIM for d in (2, 1, 0))      # numpy order: z, y, x
+
+
+@pytest.fixture(scope="module")
+def written(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("h5") / "fields.h5")
+    rng = np.random.default_rng(5)
+    phi, rhs = rng.uniform(-1, 1, SHAPE), rng.uniform(-1, 1, SHAPE)
+    st = lib().compat_h5_write(path.encode(), i3(*MX), RIM, phi, rhs, d3(-0.125, -0.25, -0.2), d3(0.125, 0.25, 0.2),
+                               17, 3.5e-7)
+    assert st == 0        # every call succeeded, and the dataset beyond the entry cap was refused
+    return path, phi, rhs
+
+
+def test_round_trip_is_bit_exact(written):
+    path, phi, rhs = written
+    a, b = np.empty(SHAPE), np.empty(SHAPE)
+    f = np.empty(SHAPE, dtype=np.float32)
+    xb, dx, ext, rev = d3(), d3(), i3(), i3()
+    it, res, pt, ok, gx1 = C.c_int(), C.c_double(), C.c_float(), C.c_int(), C.c_float()
+    names = C.create_string_buffer(256)
+    st = lib().compat_h5_read(path.encode(), i3(*MX), RIM, a, b, f, xb, dx, C.byref(it), C.byref(res), ext, rev,
+                              C.byref(pt), C.byref(ok), names, 256, C.byref(gx1))
+    assert st == 0 and ok.value == 1
+    assert np.array_equal(a, phi) and np.array_equal(b, rhs)
+    assert np.array_equal(f, phi.astype(np.float32))
+    assert it.value == 18 and res.value == 7.0e-7          # changed after the first write, the second after a reopen
+    assert list(xb) == [np.float32(-0.125), np.float32(-0.25), np.float32(-0.2)]
+    assert list(dx) == [np.float32(0.125), np.float32(0.25), np.float32(0.2)]
+    # extents come back fastest index first: x, y, z
+    assert list(ext) == [SHAPE[2], SHAPE[1], SHAPE[0]] and list(rev) == list(ext)
+    assert pt.value == np.float32(phi[3, 2, 1])             # (ix, iy, iz) = (1, 2, 3)
+    assert names.value.decode() == "phi,rhs,phi_f"
+    assert gx1.value == np.float32(np.float32(-0.125) + np.float32(0.125) * 1)
+
+
+def h5dump(*args):
+    if not os.path.exists(H5DUMP):
+        pytest.skip("no h5dump")
+    return subprocess.run([H5DUMP, *args], check=True, capture_output=True, text=True).stdout
+
+
+def test_layout_on_disk(written):
+    path, phi, _ = written
+    head = h5dump("-H", path)
+    # one group, the book-keeping attributes, the name entries of the three field writers
+    assert 'GROUP "Data"' in head
+    for name in ("Entries", "using_cbase", "Name_om00", "Name_om01", "Name_om02", "iterations", "residual",
+                 "tolerance", "solver", "mx", "delx"):
+        assert 'ATTRIBUTE "%s"' % name in head
+    assert 'ATTRIBUTE "Name_om03"' not in head       # the transposed writer registers no name
+    # datasets: slowest index first for the plain writers, as stored for the transposed one
+    z, y, x = SHAPE
+
+    def dims_of(ds):
+        m = re.search(r'DATASET "%s" \{\s*DATATYPE\s+(\S+)\s+DATASPACE\s+SIMPLE \{ \(([^)]*)\)' % ds, head)
+        assert m, ds
+        return m.group(1), [int(v) for v in m.group(2).split(",")]
+
+    assert dims_of("phi") == ("H5T_IEEE_F64LE", [z, y, x])
+    assert dims_of("rhs") == ("H5T_IEEE_F64LE", [z, y, x])
+    assert dims_of("phi_f") == ("H5T_IEEE_F32LE", [z, y, x])
+    assert dims_of("phi_T") == ("H5T_IEEE_F64LE", [x, y, z])
+    assert dims_of("history") == ("H5T_IEEE_F64LE", [3])
+    assert dims_of("data006") == ("H5T_STD_I32LE", [2])
+    assert 'DATASET "one_too_many"' not in head
+    # the counters and the string entries
+    attrs = h5dump("-a", "/Data/Entries", "-a", "/Data/using_cbase", "-a", "/Data/Name_om01", path)
+    vals = re.findall(r"\(0\): (.*)", attrs)
+    # (the refused seventh write still counts: the counter moves before the cap is tested, :1910-1913)
+    assert vals[0].strip() == "7" and vals[1].strip() == "1" and vals[2].strip() == '"rhs"'
+    assert "STRSIZE 4;" in attrs                      # "rhs" plus its terminating NUL
+    # origin and delta in x, y, z order, in the field's element type
+    o = h5dump("-a", "/Data/phi/origin", "-a", "/Data/phi_f/delta", path)
+    assert "H5T_IEEE_F64LE" in o and "H5T_IEEE_F32LE" in o
+    assert re.search(r"\(0\): -0.125, -0.25, -0.2\b", o) and re.search(r"\(0\): 0.125, 0.25, 0.2\b", o)
+    # element order: the first stored row of phi is its first x row; phi_T is the transpose
+    def values(ds, count):
+        out = h5dump("-y", "-w", "0", "-d", ds, "-s", "0,0,0", "-c", "1,1,%d" % count, "-m", "%.17g", path)
+        body = re.search(r"DATA \{(.*?)\}", out, re.S).group(1)
+        return [float(v) for v in body.replace("\n", " ").split(",")]
+
+    assert values("/Data/phi", x) == list(phi[0, 0, :])
+    assert values("/Data/phi_T", z) == list(phi[:, 0, 0])
