@@ -50,25 +50,6 @@ struct KryOp {
 	int exact_rcp;      // 1: every 2*delx_d is a power of two, x/(2d) == x*(1/(2d)) bit for bit
 };
 
-// Scalar state of the BiCGStab(l) recurrences; lives in device memory so that an
-// outer iteration needs no host round trip (solveLin_BICGStab.C:317-324).
-struct KryState {
-	double rho0, rho1, alpha, beta, omega;
-	double alpha0;               // alpha of jj = 0, kept for the phi update that k_final<2> carries
-	double sigma[KRY_LMAX + 1], gammap[KRY_LMAX + 1], gamma[KRY_LMAX + 1], gammapp[KRY_LMAX + 1];
-	double tau[KRY_LMAX + 1][KRY_LMAX + 1];
-	double norm, norm_rhs, norm_init, eps;
-	double sums[KRY_NSUMS];      // reduced dot products of the last reducing kernel
-	int iter;                    // outer iterations completed
-	int max_outer;               // 0 = unlimited
-	int done;                    // 1: converged / failed / capped; later kernels exit at once
-	int status;                  // KRY_OK, KRY_NAN_ALPHA, KRY_NAN_NORM, KRY_MAX_ITER
-	int L;
-	int local_scalars;           // 1: the reducing kernel also advances the recurrences
-	int pad_[2];
-	double hist[KRY_HIST_CAP];
-};
-
 // Mailbox all-reduce between the processes of a split domain (one GPU each).
 // Every rank owns a mailbox in uncached device memory that all peers have mapped
 // (HIP IPC).  The block that finishes a grid reduction stores its sums into slot
@@ -85,6 +66,26 @@ struct KryMail {
 	double *box;              // own mailbox: KRY_MAIL_SLOT header doubles (word 0: sequence counter),
 	                          // then [2][nranks][KRY_MAIL_SLOT]
 	double *peer[KRY_MAIL_MAX];   // every rank's mailbox as mapped into this process (peer[rank] == box)
+};
+
+// Scalar state of the BiCGStab(l) recurrences; lives in device memory so that an
+// outer iteration needs no host round trip (solveLin_BICGStab.C:317-324).
+struct KryState {
+	double rho0, rho1, alpha, beta, omega;
+	double alpha0;               // alpha of jj = 0, kept for the phi update that k_final<2> carries
+	double sigma[KRY_LMAX + 1], gammap[KRY_LMAX + 1], gamma[KRY_LMAX + 1], gammapp[KRY_LMAX + 1];
+	double tau[KRY_LMAX + 1][KRY_LMAX + 1];
+	double norm, norm_rhs, norm_init, eps;
+	double sums[KRY_NSUMS];      // reduced dot products of the last reducing kernel
+	int iter;                    // outer iterations completed
+	int max_outer;               // 0 = unlimited
+	int done;                    // 1: converged / failed / capped; later kernels exit at once
+	int status;                  // KRY_OK, KRY_NAN_ALPHA, KRY_NAN_NORM, KRY_MAX_ITER
+	int L;
+	int local_scalars;           // 1: the reducing kernel also advances the recurrences
+	int pad_[2];
+	const KryMail *mail;         // not null: sums are all-reduced over the ranks' mailboxes by the reducing kernel
+	double hist[KRY_HIST_CAP];
 };
 
 // Phases of the scalar recurrences (which dots just became available).

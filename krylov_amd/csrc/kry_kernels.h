@@ -27,7 +27,6 @@ struct KryRed {
 	KryState *S;
 	int nblk;
 	int phase;           // KryPhase run by the last block when S->local_scalars
-	const KryMail *mail; // not null: the sums are all-reduced over the ranks' mailboxes by the last block
 };
 
 struct KryFused {

@@ -165,7 +165,7 @@ template <int ND>
 __device__ inline void mail_allreduce(double (*red)[ND], const KryRed &r)
 {
 	static_assert(ND <= KRY_NSUMS, "message slot too small");
-	const KryMail *m = r.mail;
+	const KryMail *m = r.S->mail;
 	const int tid = threadIdx.x, n = m->nranks, me = m->rank;
 	__shared__ double mine[KRY_NSUMS];
 	__shared__ int failed;
@@ -270,7 +270,7 @@ __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, i
 		if (lane == 0) red[w][k] = v;
 	}
 	__syncthreads();
-	if (r.mail) {
+	if (r.S->mail) {
 		mail_allreduce<ND>(red, r);
 		return;
 	}

@@ -472,7 +472,6 @@ KryRed make_red(Slab &s, int nblk, int phase)
 	r.S = s.S;
 	r.nblk = nblk;
 	r.phase = phase;
-	r.mail = s.mail_on ? s.mail_dev : nullptr;
 	return r;
 }
 
@@ -1048,6 +1047,7 @@ int prologue(kry_solver *h)
 		init.max_outer = h->d.max_outer;
 		init.L = h->L;
 		init.local_scalars = local_scalars(h);
+			init.mail = h->slabs[0].mail_on ? h->slabs[0].mail_dev : nullptr;
 		init.norm_init = std::sqrt(ss);
 		init.norm = 1.e99;
 		if (init.norm_init < h->d.eps * h->norm_rhs) {
@@ -1081,6 +1081,7 @@ int prologue(kry_solver *h)
 			init.max_outer = h->d.max_outer;
 			init.L = h->L;
 			init.local_scalars = local_scalars(h);
+			init.mail = h->slabs[0].mail_on ? h->slabs[0].mail_dev : nullptr;
 			memcpy(s.Sh, &init, offsetof(KryState, hist));
 			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
 			HIPCHK(hipStreamSynchronize(s.st));
@@ -1643,7 +1644,9 @@ int kry_mail_enable(kry_handle h, int on)
 	drop_graph(h);
 	s.mail_on = on != 0;
 	const int ls = local_scalars(h);
+	const KryMail *mp = s.mail_on ? s.mail_dev : nullptr;
 	HIPCHK(hipMemcpy(&s.S->local_scalars, &ls, sizeof ls, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(&s.S->mail, &mp, sizeof mp, hipMemcpyHostToDevice));
 	return KRY_OK;
 }
 
