@@ -144,6 +144,30 @@ def test_mailbox_allreduce_reproduces_the_transport_allreduce(tmp_path, monkeypa
 
 
 @gpu
+def test_mailbox_allreduce_gives_up_on_an_absent_rank(tmp_path, monkeypatch):
+    """A rank whose peer never reaches the dot product stops after KRY_MAIL_TIMEOUT_MS with a
+    communication error instead of waiting for ever."""
+    import time
+    monkeypatch.setenv("KRY_TEST_MAIL", "1")
+    monkeypatch.setenv("KRY_TEST_MAIL_ABSENT", "1")
+    monkeypatch.setenv("KRY_MAIL_TIMEOUT_MS", "300")
+    port = free_port()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_slab_worker.py"), str(r), "2", str(port), "var", "2",
+                               "3", "1e-30", str(tmp_path)]) for r in range(2)]
+    try:
+        codes = [q.wait(timeout=120) for q in procs]
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    assert codes == [0, 0]
+    msg = (tmp_path / "r0.err").read_text()
+    assert "communication error" in msg, msg
+    assert time.time() - t0 < 60
+
+
+@gpu
 def test_processes_full_solve(tmp_path):
     from krylov_amd import capi
     p = make_problem("var")
