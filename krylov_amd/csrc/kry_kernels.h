@@ -40,8 +40,6 @@ struct KryFused {
 	double *O, *O2;          // stencil output (O2: second copy, KF_RES only)
 	const double *lam, *Dxx, *Dyy, *Dzz, *Dxy;
 	const double *RT, *RHS;
-	double *phi, *E;         // (unused by the current kernels)
-	const double *Ea;
 	KryRed red;
 	int zlo, zhi;            // planes on which the stencil is evaluated
 	int zc;                  // planes per chunk
@@ -52,7 +50,6 @@ struct KryFused {
 	int blk_off;             // offset of this launch's blocks in the partial-sum array
 };
 
-#define KRY_STREAM_MAXV (2 * KRY_LMAX + 3)
 struct KryStream {
 	KryGeo g;
 	KryState *S;

@@ -561,8 +561,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		if (GEN && cstore) a.Xout[pb + coff] = psi1(sx, sy, sz1, sz2);   // sx, sy, ... still hold plane z
 	};
-	// (pointwise companions of earlier versions now ride in the streaming kernels)
-	auto extras = [&](int, int, double2 &) {};
 
 	// ---- prologue: planes z0-1, z0 and the loads of z0+1 ----
 	issue(z0 - 1);
@@ -647,8 +645,6 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				out.x = rh.x - out.x;
 				out.y = rh.y - out.y;
 			}
-			double2 comp = {0., 0.};
-			extras(z, e, comp);
 			const bool m0 = mrow[e] && mxx, m1 = mrow[e] && mxy;
 			const bool o0 = orow[e] && oxx, o1 = orow[e] && oxy;
 			if (o0 && o1) {

@@ -513,7 +513,6 @@ KryFused fused_base(kry_solver *h, Slab &s, int phase)
 	a.Dxx = s.Dxx.p; a.Dyy = s.Dyy.p; a.Dzz = s.Dzz.p; a.Dxy = s.Dxy.p;
 	a.RT = s.rt.p;
 	a.RHS = s.rhs.p;
-	a.phi = s.phi.p;
 	a.zlo = t.zlo; a.zhi = t.zhi; a.zc = h->zc;
 	a.ntx = t.ntx; a.nty = t.nty; a.nchunk = t.nchunk; a.nblk = t.nblk;
 	a.ch_sel = 0;
