@@ -75,8 +75,24 @@ int main(int argc, char** argv)
 	long n = (argc > 1) ? atol(argv[1]) : 136000000L;   // ~512^3 doubles
 	n &= ~1023L;
 	std::vector<double*> bufs(12);
-	for (auto& b : bufs) { CHECK(hipMalloc(&b, n * sizeof(double) + 4096)); CHECK(hipMemset(b, 0, n * sizeof(double))); }
-	for (int nblk : {2048, 16384, 65536}) {
+	// MEMBENCH_SKEW=<bytes>: carve the arrays out of one allocation, array i starting at a
+	// multiple of 2 MiB plus i*<bytes> (0: all arrays equally aligned); unset: one hipMalloc each
+	const char* sk = getenv("MEMBENCH_SKEW");
+	if (sk) {
+		const size_t skew = (size_t)atol(sk), two_mb = 2u << 20;
+		const size_t slot = ((n * sizeof(double) + 12 * skew + two_mb) / two_mb + 1) * two_mb;
+		char* base = nullptr;
+		CHECK(hipMalloc(&base, slot * 12 + two_mb));
+		CHECK(hipMemset(base, 0, slot * 12 + two_mb));
+		base = (char*)(((size_t)base + two_mb - 1) / two_mb * two_mb);
+		for (size_t i = 0; i < bufs.size(); ++i) bufs[i] = (double*)(base + i * slot + i * skew);
+		printf("arrays carved from one allocation, skew %zu bytes\n", skew);
+	} else {
+		for (auto& b : bufs) { CHECK(hipMalloc(&b, n * sizeof(double) + 4096)); CHECK(hipMemset(b, 0, n * sizeof(double))); }
+		for (auto& b : bufs) printf("%p ", (void*)b);
+		printf("\n");
+	}
+	for (int nblk : {16384, 65536}) {
 		run<1, 1, false, 4>(bufs, n, nblk, "copy");
 		run<1, 1, true, 4>(bufs, n, nblk, "copy nontemporal");
 		run<1, 0, false, 4>(bufs, n, nblk, "read");
