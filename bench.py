@@ -263,10 +263,13 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag[0]) == 1
 
-    # Dot products: all-reduced by the transport (one RCCL call and two small kernels per
-    # reduction) or by the reduction kernels themselves through device mailboxes.  Both are
-    # tried on a few passes of this very problem; the faster one that gives the same
-    # residuals is used for the measurement.  KRY_BENCH_REDUCE=transport|mailbox skips the trial.
+    # Exchange between the ranks: through the transport (per dot product one RCCL all-reduce and
+    # two small kernels, per operator output one grouped send/receive), with the dot products
+    # all-reduced by the reduction kernels themselves through device mailboxes ("mailbox"), or
+    # with the ghost planes travelling through mapped device memory as well ("mapped memory").
+    # All are tried on a few passes of this very problem; the fastest one that reproduces the
+    # transport's residuals is used for the measurement.  KRY_BENCH_REDUCE=transport skips the
+    # trial, =mailbox / ="mapped memory" prefers that route when it is valid.
     reduction, trial = "none", None
     if world > 1:
         reduction = "transport"
@@ -289,10 +292,12 @@ def main():
                     sys.stderr.write("rank %d: mailboxes not connected (%s)\n" % (rank, e))
             if not all_ok(connected):
                 if connected:
-                    solver.mail_enable(False)
+                    solver.mail_enable(0)
             else:
                 trial, hists = {}, {}
-                for name, on in (("mailbox", True), ("transport", False)):
+                modes = {"mailbox": capi.KRY_MAIL_SUMS, "mapped memory": capi.KRY_MAIL_SUMS | capi.KRY_MAIL_PLANES,
+                         "transport": 0}
+                for name, on in modes.items():
                     solver.mail_enable(on)
                     barrier()
                     good, dt = True, float("inf")
@@ -305,19 +310,21 @@ def main():
                         dt = time.perf_counter() - t0
                         hists[name] = solver.history()[:8]
                     except Exception as e:
-                        sys.stderr.write("rank %d: %s reduction failed (%s)\n" % (rank, name, e))
+                        sys.stderr.write("rank %d: exchange by %s failed (%s)\n" % (rank, name, e))
                         good = False
                     tt = torch.tensor([dt if good else float("inf")], dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     trial[name] = float(tt[0]) / 6 * 1e3
-                same = (len(hists) == 2 and len(hists["mailbox"]) == len(hists["transport"]) == 8 and
-                        bool(np.all(np.abs(hists["mailbox"][:3] - hists["transport"][:3])
-                                    <= 1e-9 * np.abs(hists["transport"][:3]))))
-                use_mail = all_ok(same) and trial["mailbox"] < trial["transport"]
-                if want == "mailbox" and all_ok(same):
-                    use_mail = True
-                solver.mail_enable(use_mail)
-                reduction = "mailbox" if use_mail else "transport"
+                ref = hists.get("transport")
+                best = "transport"
+                for name in ("mailbox", "mapped memory"):
+                    hh = hists.get(name)
+                    same = (ref is not None and hh is not None and len(hh) == len(ref) == 8 and
+                            bool(np.all(np.abs(hh[:3] - ref[:3]) <= 1e-9 * np.abs(ref[:3]))))
+                    if all_ok(same) and (trial[name] < trial[best] or want == name):
+                        best = name
+                solver.mail_enable(modes[best])
+                reduction = best
         barrier()
 
     t_stage = time.perf_counter()
@@ -381,8 +388,8 @@ def main():
                                                      "mixed Dirichlet/extrapolating" if args.workload == "mixed"
                                                      else "Dirichlet", world),
                        "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world,
-                       "transport": transport, "reduction": reduction,
-                       "reduction_trial_ms_per_pass": trial},
+                       "transport": transport, "exchange": reduction,
+                       "exchange_trial_ms_per_pass": trial},
             "valid": bool(ok), "solver_path": s1.fused,
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),

@@ -156,13 +156,20 @@ int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allredu
  *                     (KRY_MAIL_HANDLE_BYTES bytes) to `handle`;
  *   kry_mail_connect: `handles` = the nranks handles in rank order (all-gathered by the
  *                     caller); maps the peers' mailboxes and switches the path on;
- *   kry_mail_enable:  switches it off / on again (between solves).
+ *   kry_mail_enable:  chooses what travels this way (between solves): KRY_MAIL_SUMS, the dot
+ *                     products; KRY_MAIL_PLANES, also the ghost planes (the reference:
+ *                     BICGStab3D/BoundaryHandler.C:1633-1677) -- the sender's kernel stores its
+ *                     planes into landing slots of the neighbour's memory and raises a sequence
+ *                     word, the receiver's kernel waits for the word and fills its ghost cells;
+ *                     0 returns to the transport.  kry_mail_connect leaves KRY_MAIL_SUMS on.
  * A rank that waits longer than KRY_MAIL_TIMEOUT_MS (default 30000) for a peer stops
  * the solve with KRY_ERR_COMM.  At most 64 ranks. */
 #define KRY_MAIL_HANDLE_BYTES 64
+#define KRY_MAIL_SUMS   1
+#define KRY_MAIL_PLANES 2
 int kry_mail_export(kry_handle h, void *handle);
 int kry_mail_connect(kry_handle h, int rank, int nranks, const void *handles);
-int kry_mail_enable(kry_handle h, int on);
+int kry_mail_enable(kry_handle h, int what);
 
 /* Replaces BICGStab::solve(bounds, phi, rhs, lambda, D_xx, D_yy, D_zz, debug)
  * (BICGStab3D/solveLin_BICGStab.C:200-215).  phi: initial guess in, solution

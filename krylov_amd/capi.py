@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libkrylov_amd.so")
 KRY_MAX_SLABS = 16
 KRY_UID_BYTES = 128
 KRY_MAIL_HANDLE_BYTES = 64
+KRY_MAIL_SUMS, KRY_MAIL_PLANES = 1, 2
 KRY_FORCE_GENERIC = 1
 
 STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reached",
@@ -255,8 +256,10 @@ class Solver:
         buf = C.create_string_buffer(blob, len(blob))
         _check(lib().kry_mail_connect(self._h, rank, nranks, buf), "kry_mail_connect")
 
-    def mail_enable(self, on):
-        _check(lib().kry_mail_enable(self._h, int(bool(on))), "kry_mail_enable")
+    def mail_enable(self, what):
+        """0: everything through the transport; KRY_MAIL_SUMS: dot products through the mailboxes;
+        KRY_MAIL_SUMS | KRY_MAIL_PLANES: the ghost planes through mapped memory as well."""
+        _check(lib().kry_mail_enable(self._h, int(what)), "kry_mail_enable")
 
     def solve_const(self, phi, rhs, lam, Dc, debug=0):
         return _check(lib().kry_solve_const(self._h, phi, rhs, lam, Dc[0], Dc[1], Dc[2], debug),

@@ -1,4 +1,5 @@
 #include "kry_comm.h"
+#include "kry_kernels.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -137,6 +138,10 @@ void KryComm::destroy()
 	stage_cap_ = 0;
 	if (comm_ && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(comm_));
 	comm_ = nullptr;
+	if (link_ticket_) hipFree(link_ticket_);
+	link_ticket_ = nullptr;
+	link_on_ = false;
+	link_self_ = nullptr;
 }
 
 int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
@@ -159,10 +164,62 @@ int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
 	return 0;
 }
 
+// Link area of a rank: [mailbox of the all-reduce | sequence words [3 dirs][2 sides] | landing
+// slots [3 dirs][2 sides][2 parities][cap doubles]].  Side 0 receives from the lower
+// neighbour, side 1 from the upper one.
+size_t KryComm::link_flag_offset()
+{
+	const size_t mail = sizeof(double) * KRY_MAIL_SLOT * (1 + 2 * (size_t)KRY_MAIL_MAX);
+	return (mail + 255) / 256 * 256;
+}
+static size_t link_slot_offset(size_t cap, int dir, int side, int par)
+{
+	return KryComm::link_flag_offset() + 256 + (size_t)((dir * 2 + side) * 2 + par) * cap * sizeof(double);
+}
+size_t KryComm::link_bytes(size_t cap) { return link_slot_offset(cap, 3, 0, 0); }
+
+int KryComm::set_link(int rank, char *self, const std::vector<char *> &peer, size_t cap, long long timeout, KryState *S)
+{
+	if (!link_ticket_) {
+		if (hipMalloc((void **)&link_ticket_, 64) != hipSuccess || hipMemset(link_ticket_, 0, 64) != hipSuccess) {
+			g_cerr = "cannot allocate the link's ticket";
+			return -2;
+		}
+	}
+	rank_ = rank;
+	link_self_ = self;
+	link_peer_ = peer;
+	link_cap_ = cap;
+	link_timeout_ = timeout;
+	link_S_ = S;
+	return 0;
+}
+
 int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_hi, const double *send_hi,
-                  double *recv_hi, size_t count, hipStream_t st)
+                  double *recv_hi, size_t count, hipStream_t st, int dir)
 {
 	if (peer_lo < 0 && peer_hi < 0) return 0;
+	if (link_on_) {
+		if (count > link_cap_ || dir < 0 || dir > 2) { g_cerr = "halo larger than the link's landing slots"; return -1; }
+		const unsigned long long seq = ++link_seq_[dir];
+		const int par = (int)(seq & 1ull);
+		auto slot = [&](char *base, int side) { return (double *)(base + link_slot_offset(link_cap_, dir, side, par)); };
+		auto flag = [&](char *base, int side) {
+			return (unsigned long long *)(base + link_flag_offset()) + (dir * 2 + side);
+		};
+		// towards the lower neighbour this rank is the upper one (side 1 there), and vice versa
+		char *plo = peer_lo >= 0 ? link_peer_[peer_lo] : nullptr, *phi = peer_hi >= 0 ? link_peer_[peer_hi] : nullptr;
+		if (kry_launch_halo_push(plo ? send_lo : nullptr, plo ? slot(plo, 1) : nullptr, plo ? flag(plo, 1) : nullptr,
+		                         phi ? send_hi : nullptr, phi ? slot(phi, 0) : nullptr, phi ? flag(phi, 0) : nullptr, count,
+		                         seq, link_ticket_, st) != hipSuccess ||
+		    kry_launch_halo_pull(plo ? recv_lo : nullptr, plo ? slot(link_self_, 0) : nullptr, flag(link_self_, 0),
+		                         phi ? recv_hi : nullptr, phi ? slot(link_self_, 1) : nullptr, flag(link_self_, 1), count,
+		                         seq, link_timeout_, link_S_, st) != hipSuccess) {
+			g_cerr = "launch of the ghost-plane kernels failed";
+			return -2;
+		}
+		return 0;
+	}
 	if (cb_halo_ && cb_host_) {
 		if (ensure_stage(count) != 0) return -2;
 		double *slo = stage_, *shi = stage_ + count, *rlo = stage_ + 2 * count, *rhi = stage_ + 3 * count;

@@ -5,6 +5,9 @@
 
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <vector>
+
+struct KryState;
 
 class KryComm {
 public:
@@ -30,8 +33,18 @@ public:
 	int allreduce_sum(double *buf, int n, hipStream_t st);
 	// send `count` doubles to / receive from the lower and upper neighbour
 	// (peer < 0: no neighbour on that side), one grouped call queued on `st`
+	// `dir`: 0, 1, 2 = the exchange runs along x, y, z (landing slots are kept per direction)
 	int halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_hi, const double *send_hi,
-	         double *recv_hi, size_t count, hipStream_t st);
+	         double *recv_hi, size_t count, hipStream_t st, int dir = 2);
+
+	// Ghost planes through device memory the ranks have mapped from each other instead of
+	// the transport: `self` / `peer[r]` are the ranks' link areas (this rank's own and as
+	// mapped here), laid out as link_bytes() describes; `cap` doubles per landing slot.
+	static size_t link_flag_offset();
+	static size_t link_bytes(size_t cap);
+	int set_link(int rank, char *self, const std::vector<char *> &peer, size_t cap, long long timeout, KryState *S);
+	void link_planes(bool on) { link_on_ = on && link_self_ != nullptr; }
+	bool link_planes() const { return link_on_; }
 
 private:
 	void *comm_ = nullptr;
@@ -43,4 +56,13 @@ private:
 	size_t stage_cap_ = 0;
 	int ensure_stage(size_t count);
 	int rank_ = 0, nranks_ = 1;
+	// mapped-memory link
+	bool link_on_ = false;
+	char *link_self_ = nullptr;
+	std::vector<char *> link_peer_;
+	size_t link_cap_ = 0;
+	unsigned long long link_seq_[3] = {0, 0, 0};
+	unsigned *link_ticket_ = nullptr;
+	long long link_timeout_ = 0;
+	KryState *link_S_ = nullptr;
 };

@@ -73,6 +73,12 @@ hipError_t kry_launch_sum_slabs(const double *gather, int nslabs, double *out, h
 hipError_t kry_launch_axpy(double *dst, const double *x, const double *y, double c, long n, hipStream_t st);
 hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int px, bool to_device, hipStream_t st);
 hipError_t kry_launch_face(double *field, double *buf, const KryGeo &g, int dir, int idx, bool to_buf, hipStream_t st);
+hipError_t kry_launch_halo_push(const double *send_lo, double *slot_lo, unsigned long long *flag_lo, const double *send_hi,
+                                double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
+                                unsigned *ticket, hipStream_t st);
+hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned long long *flag_lo, double *recv_hi,
+                                const double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
+                                long long timeout, KryState *S, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,

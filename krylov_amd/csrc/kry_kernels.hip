@@ -1014,6 +1014,74 @@ __global__ __launch_bounds__(NT) void g_face(double *field, double *buf, KryGeo 
 	}
 }
 
+// Ghost-plane exchange between processes through mapped device memory.
+// k_halo_push copies this rank's planes into the neighbours' landing slots (stores that
+// travel over the GPU interconnect) and, when the whole grid has done so, raises the
+// neighbours' sequence words; k_halo_pull waits for this rank's own sequence words and
+// copies the landed planes into the ghost cells.  A side without neighbour has null
+// pointers.  The sequence words only grow, and a slot is reused every second exchange.
+struct KryHaloSide {
+	const double *src;              // push: own plane            pull: own landing slot
+	double *dst;                    // push: neighbour's slot     pull: own ghost plane
+	unsigned long long *flag;       // push: neighbour's word     pull: own word
+};
+
+__device__ inline void halo_copy(const KryHaloSide &sd, size_t count)
+{
+	const size_t start = (size_t)blockIdx.x * NT + threadIdx.x, stride = (size_t)gridDim.x * NT;
+	const bool vec = ((count & 1) == 0) && (((size_t)sd.src | (size_t)sd.dst) & 15) == 0;
+	if (vec) {
+		for (size_t q = start; q < count / 2; q += stride) st2s(sd.dst + 2 * q, ld2s(sd.src + 2 * q));
+	} else {
+		for (size_t q = start; q < count; q += stride) st1s(sd.dst + q, __builtin_nontemporal_load(sd.src + q));
+	}
+}
+
+__global__ __launch_bounds__(NT) void k_halo_push(KryHaloSide lo, KryHaloSide hi, size_t count, unsigned long long seq,
+                                                  unsigned *ticket)
+{
+	if (lo.src) halo_copy(lo, count);
+	if (hi.src) halo_copy(hi, count);
+	__threadfence_system();          // this thread's stores have reached the neighbour's memory
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (t == gridDim.x - 1) {
+			__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (lo.src) __hip_atomic_store(lo.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			if (hi.src) __hip_atomic_store(hi.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
+__global__ __launch_bounds__(NT) void k_halo_pull(KryHaloSide lo, KryHaloSide hi, size_t count, unsigned long long seq,
+                                                  long long timeout, KryState *S)
+{
+	__shared__ int failed;
+	if (threadIdx.x == 0) {
+		int bad = 0;
+		const long long t0 = wall_clock64();
+		unsigned spins = 0;
+		for (int side = 0; side < 2 && !bad; ++side) {
+			const unsigned long long *f = side ? hi.flag : lo.flag;
+			if (!(side ? hi.src : lo.src)) continue;
+			while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+				__builtin_amdgcn_s_sleep(4);
+				if ((++spins & 255u) == 0u && wall_clock64() - t0 > timeout) { bad = 1; break; }
+			}
+		}
+		failed = bad;
+	}
+	__syncthreads();
+	if (failed) {
+		// the neighbour never delivered: stop the solve, the kernels queued behind exit at once
+		if (threadIdx.x == 0 && blockIdx.x == 0) { S->status = -3; S->done = 1; }
+		return;
+	}
+	if (lo.src) halo_copy(lo, count);
+	if (hi.src) halo_copy(hi, count);
+}
+
 // dst = a - b (Krylov.C:259)
 __global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const double *y, long n2)
 {
@@ -1270,6 +1338,26 @@ hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int 
 {
 	hipLaunchKernelGGL(g_repack, dim3((unsigned)std::min<long>((rows + NW - 1) / NW, 32768)), dim3(NT), 0, st, dev, packed, w,
 	                   rows, px, to_device ? 1 : 0);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_halo_push(const double *send_lo, double *slot_lo, unsigned long long *flag_lo, const double *send_hi,
+                                double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
+                                unsigned *ticket, hipStream_t st)
+{
+	KryHaloSide lo = {send_lo, slot_lo, flag_lo}, hi = {send_hi, slot_hi, flag_hi};
+	const int nb = (int)std::max<size_t>(1, std::min<size_t>((count / 2 + NT - 1) / NT, 256));
+	hipLaunchKernelGGL(k_halo_push, dim3(nb), dim3(NT), 0, st, lo, hi, count, seq, ticket);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned long long *flag_lo, double *recv_hi,
+                                const double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
+                                long long timeout, KryState *S, hipStream_t st)
+{
+	KryHaloSide lo = {slot_lo, recv_lo, flag_lo}, hi = {slot_hi, recv_hi, flag_hi};
+	const int nb = (int)std::max<size_t>(1, std::min<size_t>((count / 2 + NT - 1) / NT, 128));
+	hipLaunchKernelGGL(k_halo_pull, dim3(nb), dim3(NT), 0, st, lo, hi, count, seq, timeout, S);
 	return hipGetLastError();
 }
 

@@ -89,6 +89,7 @@ struct Slab {
 	KryMail *mail_dev = nullptr;       // its description for the kernels
 	std::vector<void *> mail_mapped;   // peers' mailboxes as opened here
 	bool mail_on = false;
+	size_t link_cap = 0;               // doubles per landing slot of the ghost-plane exchange
 	std::vector<Field *> all;
 };
 
@@ -358,7 +359,7 @@ int exchange_xy(kry_solver *h, double *f)
 			HIPCHK(kry_launch_face(f, send_hi, g, dir, m - 1, true, s.st));
 			if (nl == 2) HIPCHK(kry_launch_face(f, send_hi + n, g, dir, m - 2, true, s.st));
 		}
-		CHK(h->comm.halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (size_t)nl * n, s.st));
+		CHK(h->comm.halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (size_t)nl * n, s.st, dir));
 		if (peer_hi >= 0) {
 			HIPCHK(kry_launch_face(f, recv_hi, g, dir, m + 1, false, s.st));
 			if (nl == 2) HIPCHK(kry_launch_face(f, recv_hi + n, g, dir, m, false, s.st));
@@ -1582,8 +1583,10 @@ int kry_mail_export(kry_handle h, void *handle)
 	HIPCHK(hipSetDevice(s.device));
 	if (!s.mail_box) {
 		// uncached, so that what a peer GPU stores is seen by a kernel already running here
-		HIPCHK(hipExtMallocWithFlags((void **)&s.mail_box, mail_bytes(KRY_MAIL_MAX), hipDeviceMallocUncached));
-		HIPCHK(hipMemset(s.mail_box, 0, mail_bytes(KRY_MAIL_MAX)));
+		// behind the mailbox: the landing slots of the ghost-plane exchange (KryComm::link_bytes)
+		s.link_cap = std::max<size_t>((size_t)s.g.ps, 2 * s.xy_plane);
+		HIPCHK(hipExtMallocWithFlags((void **)&s.mail_box, KryComm::link_bytes(s.link_cap), hipDeviceMallocUncached));
+		HIPCHK(hipMemset(s.mail_box, 0, KryComm::link_bytes(s.link_cap)));
 	}
 	hipIpcMemHandle_t hd;
 	HIPCHK(hipIpcGetMemHandle(&hd, s.mail_box));
@@ -1630,7 +1633,13 @@ int kry_mail_connect(kry_handle h, int rank, int nranks, const void *handles)
 	}
 	HIPCHK(hipMalloc((void **)&s.mail_dev, sizeof m));
 	HIPCHK(hipMemcpy(s.mail_dev, &m, sizeof m, hipMemcpyHostToDevice));
-	return kry_mail_enable(h, 1);
+	std::vector<char *> bases(nranks);
+	for (int r = 0; r < nranks; ++r) bases[r] = (char *)m.peer[r];
+	if (h->comm.set_link(rank, (char *)s.mail_box, bases, s.link_cap, m.timeout, s.S) < 0) {
+		set_err("%s", KryComm::last_error());
+		return KRY_ERR_HIP;
+	}
+	return kry_mail_enable(h, KRY_MAIL_SUMS);
 }
 
 int kry_mail_enable(kry_handle h, int on)
@@ -1641,7 +1650,8 @@ int kry_mail_enable(kry_handle h, int on)
 	HIPCHK(hipSetDevice(s.device));
 	HIPCHK(hipStreamSynchronize(s.st));
 	drop_graph(h);
-	s.mail_on = on != 0;
+	s.mail_on = (on & KRY_MAIL_SUMS) != 0;
+	h->comm.link_planes((on & KRY_MAIL_PLANES) != 0);
 	const int ls = local_scalars(h);
 	const KryMail *mp = s.mail_on ? s.mail_dev : nullptr;
 	HIPCHK(hipMemcpy(&s.S->local_scalars, &ls, sizeof ls, hipMemcpyHostToDevice));

@@ -55,10 +55,12 @@ def main():
             s.comm_init(uid[0], rank, world)
         else:
             s.comm_init_callbacks(rank, world, allreduce, halo)
-        if os.environ.get("KRY_TEST_MAIL") == "1":         # dot products all-reduced through device mailboxes
+        mail = int(os.environ.get("KRY_TEST_MAIL", "0"))   # 1: dot products through device mailboxes, 2: ghost
+        if mail:                                            # planes through mapped memory, 3: both
             handles = [None] * world
             dist.all_gather_object(handles, s.mail_export())
             s.mail_connect(rank, world, handles)
+            s.mail_enable(mail)
         if os.environ.get("KRY_TEST_MAIL_ABSENT") == "1":  # the last rank never shows up at the first dot product
             import time
             if rank == world - 1:
