@@ -178,6 +178,28 @@ void BICGStab::ensure_handle(BoundaryHandler3D &bounds, const NumMatrix<double, 
 		cerr << " BICGStab: cannot attach the MPI transport (" << kry_last_error() << ")" << endl;
 		exit(2);
 	}
+	// Processes that share a node let their GPUs exchange the dot products and ghost planes among
+	// themselves through mapped device memory; MPI stays attached as the fallback and carries the
+	// set-up (KRY_MAIL=0 keeps everything on MPI).
+	const char *mail_env = getenv("KRY_MAIL");
+	if (ntasks_mpi > 1 && !(mail_env && atoi(mail_env) == 0)) {
+		MPI_Comm node;
+		int node_size = 0;
+		MPI_Comm_split_type(comm3d, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
+		MPI_Comm_size(node, &node_size);
+		MPI_Comm_free(&node);
+		int ok = (node_size == ntasks_mpi && ntasks_mpi <= 64) ? 1 : 0, all_ok = 0;
+		std::vector<char> mine(KRY_MAIL_HANDLE_BYTES, 0), all((size_t)KRY_MAIL_HANDLE_BYTES * ntasks_mpi, 0);
+		if (ok && kry_mail_export(handle, mine.data()) != 0) ok = 0;
+		MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm3d);
+		if (all_ok) {
+			MPI_Allgather(mine.data(), KRY_MAIL_HANDLE_BYTES, MPI_BYTE, all.data(), KRY_MAIL_HANDLE_BYTES, MPI_BYTE, comm3d);
+			ok = kry_mail_connect(handle, rank, ntasks_mpi, all.data()) == 0 ? 1 : 0;
+			MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm3d);
+			if (ok) kry_mail_enable(handle, all_ok ? (KRY_MAIL_SUMS | KRY_MAIL_PLANES) : 0);
+		}
+		device_link = all_ok != 0;
+	}
 #endif
 }
 

@@ -330,6 +330,9 @@ int main(int argc, char *argv[])
 		cout << "Runtime (solver) : " << (long long)runtime << " ms" << endl;
 		cout << "Iterations       : " << bs->iterations() << " (" << bs->solveRuntime() << " ms on the device, "
 		     << (bs->usedFusedKernels() ? "fused" : "generic") << " kernels)" << endl;
+#ifdef parallel
+		cout << "Exchange         : " << (bs->usesDeviceLink() ? "device memory mapped between the processes" : "MPI") << endl;
+#endif
 	}
 	delete lin_solver;
 #ifdef parallel

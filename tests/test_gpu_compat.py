@@ -127,6 +127,18 @@ def test_parallel_driver_under_mpi(test, nproc, grid):
     ia = int(re.search(r"Iterations\s*:\s*(\d+)", serial.stdout).group(1))
     ib = int(re.search(r"Iterations\s*:\s*(\d+)", par.stdout).group(1))
     assert abs(ia - ib) <= max(6, ia // 3)
+    # the processes share a node: their GPUs exchange among themselves
+    assert "Exchange         : device memory mapped between the processes" in par.stdout
+    # and with MPI as the only carrier the iteration is the same up to the order in which
+    # MPI_Allreduce adds the ranks' sums (the device link adds them in rank order)
+    if nproc <= 4:
+        env = dict(os.environ, KRY_MAIL="0")
+        mpi = subprocess.run([MPIEXEC, "-n", str(nproc), DRIVER_MPI, "-n", "32", "-t", str(test), "-q"] + extra,
+                             capture_output=True, text=True, timeout=240, env=env)
+        assert mpi.returncode == 0, mpi.stdout + mpi.stderr
+        assert "Exchange         : MPI" in mpi.stdout
+        assert _l2(mpi.stdout) == pytest.approx(b, rel=1e-3)
+        assert abs(int(re.search(r"Iterations\s*:\s*(\d+)", mpi.stdout).group(1)) - ib) <= max(6, ia // 3)
 
 
 def test_opencl_solver_style_class():
