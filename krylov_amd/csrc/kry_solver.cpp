@@ -1473,10 +1473,14 @@ void kry_destroy(kry_handle h)
 {
 	if (!h) return;
 	drop_graph(h);
-	h->comm.destroy();
 	for (Slab &s : h->slabs) {
 		hipSetDevice(s.device);
 		if (s.st) hipStreamSynchronize(s.st);
+		if (s.st_comm) hipStreamSynchronize(s.st_comm);
+	}
+	h->comm.destroy();
+	for (Slab &s : h->slabs) {
+		hipSetDevice(s.device);
 		free_fields(s);
 		if (s.S) hipFree(s.S);
 		if (s.Sh) hipHostFree(s.Sh);
