@@ -151,7 +151,8 @@ int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allredu
  * The block that finishes a reduction kernel stores its sums into every rank's mailbox
  * and adds the ranks' contributions in rank order itself: no extra kernel launch per
  * dot product, and the same bits on every rank.  The transport set with kry_comm_init*
- * is still required: it carries the ghost planes unless KRY_MAIL_PLANES is chosen too.
+ * carries the ghost planes unless KRY_MAIL_PLANES is chosen too; with both chosen no
+ * transport is needed at all (kry_mail_connect on a handle without one chooses both).
  *   kry_mail_export:  creates this rank's mailbox and landing slots, writes their HIP IPC handle
  *                     (KRY_MAIL_HANDLE_BYTES bytes) to `handle`;
  *   kry_mail_connect: `handles` = the nranks handles in rank order (all-gathered by the

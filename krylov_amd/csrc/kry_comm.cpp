@@ -160,6 +160,7 @@ int KryComm::allreduce_sum(double *buf, int n, hipStream_t st)
 		if (cb_allreduce_(cb_ctx_, buf, n) != 0) { g_cerr = "allreduce callback failed"; return -3; }
 		return 0;
 	}
+	if (!comm_) { g_cerr = "no transport attached for the all-reduce"; return -3; }
 	NCHK(g_api.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, static_cast<ncclComm_t>(comm_), st));
 	return 0;
 }
@@ -187,6 +188,7 @@ int KryComm::set_link(int rank, char *self, const std::vector<char *> &peer, siz
 		}
 	}
 	rank_ = rank;
+	nranks_ = (int)peer.size();
 	link_self_ = self;
 	link_peer_ = peer;
 	link_cap_ = cap;
@@ -247,6 +249,7 @@ int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_
 		}
 		return 0;
 	}
+	if (!comm_) { g_cerr = "no transport attached for the ghost planes"; return -3; }
 	ncclComm_t c = static_cast<ncclComm_t>(comm_);
 	NCHK(g_api.GroupStart());
 	if (peer_lo >= 0) {

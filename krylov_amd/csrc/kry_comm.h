@@ -25,7 +25,8 @@ public:
 	// the same with HOST pointers: the data is staged through pinned buffers here
 	int init_host_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx);
 	void destroy();
-	bool active() const { return comm_ != nullptr || cb_allreduce_ != nullptr; }
+	bool active() const { return comm_ != nullptr || cb_allreduce_ != nullptr || link_self_ != nullptr; }
+	bool has_transport() const { return comm_ != nullptr || cb_allreduce_ != nullptr; }
 	int rank() const { return rank_; }
 	int nranks() const { return nranks_; }
 

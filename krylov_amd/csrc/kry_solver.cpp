@@ -1643,7 +1643,8 @@ int kry_mail_connect(kry_handle h, int rank, int nranks, const void *handles)
 		set_err("%s", KryComm::last_error());
 		return KRY_ERR_HIP;
 	}
-	return kry_mail_enable(h, KRY_MAIL_SUMS);
+	// without a transport everything has to travel through the mapped memory
+	return kry_mail_enable(h, h->comm.has_transport() ? KRY_MAIL_SUMS : (KRY_MAIL_SUMS | KRY_MAIL_PLANES));
 }
 
 int kry_mail_enable(kry_handle h, int on)
@@ -1654,6 +1655,10 @@ int kry_mail_enable(kry_handle h, int on)
 	HIPCHK(hipSetDevice(s.device));
 	HIPCHK(hipStreamSynchronize(s.st));
 	drop_graph(h);
+	if (!h->comm.has_transport() && on != (KRY_MAIL_SUMS | KRY_MAIL_PLANES)) {
+		set_err("kry_mail_enable: no transport is attached that could carry the rest");
+		return KRY_ERR_STATE;
+	}
 	s.mail_on = (on & KRY_MAIL_SUMS) != 0;
 	h->comm.link_planes((on & KRY_MAIL_PLANES) != 0);
 	const int ls = local_scalars(h);

@@ -146,6 +146,21 @@ def test_mapped_memory_exchange_reproduces_the_transport(tmp_path, monkeypatch, 
 
 
 @gpu
+@pytest.mark.parametrize("world,kind,nproc", [(4, "var", None), (4, "mixed32", (2, 2, 1))])
+def test_mapped_memory_alone_needs_no_transport(tmp_path, monkeypatch, world, kind, nproc):
+    """No communicator, no callbacks: connected mailboxes and landing slots carry everything."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    plain = run_ranks(world, kind, 2, 4, 1e-30, str(tmp_path / "a"), nproc)
+    monkeypatch.setenv("KRY_TEST_MAIL", "3")
+    monkeypatch.setenv("KRY_TEST_NO_TRANSPORT", "1")
+    alone = run_ranks(world, kind, 2, 4, 1e-30, str(tmp_path / "b"), nproc)
+    for a, b in zip(plain, alone):
+        assert int(b["iters"]) == 4
+        assert np.array_equal(a["hist"], b["hist"]) and np.array_equal(a["phi"], b["phi"])
+
+
+@gpu
 def test_mailbox_allreduce_gives_up_on_an_absent_rank(tmp_path, monkeypatch):
     """A rank whose peer never reaches the dot product stops after KRY_MAIL_TIMEOUT_MS with a
     communication error instead of waiting for ever."""
