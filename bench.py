@@ -205,6 +205,7 @@ def main():
     # per-kernel HIP events only where the roofline is reported (one GPU)
     os.environ.setdefault("KRY_PROFILE", "1" if world == 1 else "0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: the control plane stays on loopback
 
     # the solver library first (it binds the ROCm installation's HIP runtime),
     # torch.distributed afterwards and for the control plane only
