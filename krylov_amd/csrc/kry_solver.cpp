@@ -1459,7 +1459,10 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + h->ty - 1) / h->ty);
 		const int chunks = std::max(1, (1024 + tiles - 1) / tiles);
 		// (small grids: short chunks, the march over a chunk's planes is a latency chain)
-		h->zc = std::min(64, std::max(g.mz <= 64 ? 2 : 4, (g.mz + chunks - 1) / chunks));
+		// (planes a stencil kernel evaluates: the faces of the domain are skipped on Dirichlet
+		// faces, interface planes and general faces are not; equal on all slabs of a split)
+		const int nz = (h->gen || h->np[2] > 1) ? g.mz + 1 : g.mz - 1;
+		h->zc = std::min(64, std::max(g.mz <= 64 ? 2 : 4, (nz + chunks - 1) / chunks));
 	}
 	if (st < 0) {
 		kry_destroy(h);
