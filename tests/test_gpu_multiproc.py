@@ -146,6 +146,21 @@ def test_mapped_memory_exchange_reproduces_the_transport(tmp_path, monkeypatch, 
 
 
 @gpu
+@pytest.mark.parametrize("world,kind,nproc", [(4, "var", None), (8, "var", (2, 2, 2))])
+def test_mapped_memory_exchange_over_many_passes(tmp_path, monkeypatch, world, kind, nproc):
+    """150 passes (900 all-reduces, 600 and more plane exchanges per rank, slots and sequence words
+    reused throughout): still the transport's history, bit for bit."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    plain = run_ranks(world, kind, 2, 150, 1e-30, str(tmp_path / "a"), nproc)
+    monkeypatch.setenv("KRY_TEST_MAIL", "3")
+    mail = run_ranks(world, kind, 2, 150, 1e-30, str(tmp_path / "b"), nproc)
+    for a, b in zip(plain, mail):
+        assert int(a["iters"]) == int(b["iters"]) and int(b["iters"]) > 20
+        assert np.array_equal(a["hist"], b["hist"]) and np.array_equal(a["phi"], b["phi"])
+
+
+@gpu
 @pytest.mark.parametrize("world,kind,nproc", [(4, "var", None), (4, "mixed32", (2, 2, 1))])
 def test_mapped_memory_alone_needs_no_transport(tmp_path, monkeypatch, world, kind, nproc):
     """No communicator, no callbacks: connected mailboxes and landing slots carry everything."""
