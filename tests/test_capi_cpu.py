@@ -70,3 +70,15 @@ def _device_count():
 def test_no_cpu_fallback_without_a_device():
     with pytest.raises(capi.KryError, match="no HIP device"):
         capi.Solver((16, 16, 16), (1 / 16,) * 3)
+
+
+def test_header_and_library_serve_a_plain_c99_caller(tmp_path):
+    """The C ABI from C, not C++: examples/solve_poisson.c compiles with -std=c99 -pedantic -Werror
+    against include/krylov_amd.h and links against the library (run on the GPU by test_gpu_compat)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "solve_poisson")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "solve_poisson.c"), "-L", os.path.join(root, "krylov_amd"),
+                    "-lkrylov_amd", "-lm", "-o", out], check=True, capture_output=True, text=True)
+    assert os.path.getsize(out) > 0
