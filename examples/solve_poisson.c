@@ -1,8 +1,11 @@
-/* Plain C99 caller of the C ABI: the 64^3 Poisson problem with Dirichlet faces
- * (D = (1,1,1), lambda = 0, rhs = -3 pi^2 sin(pi x) sin(pi y) sin(pi z) on [0,1]^3, the
- * constant-coefficient overload of the reference's solver, BICGStab3D/solveLin_BICGStab.C:200-215,
- * on its driver's analytic solution, BICGStab3D/main.C:276-284), solved to 1e-6 and compared
- * with sin(pi x) sin(pi y) sin(pi z).
+/* Plain C99 caller of the C ABI: test 1 of the reference's driver (BICGStab3D/main.C:223-229,
+ * 243, 276-284) -- constant diffusion D = (1,1,10), lambda = 0.2 x y^2 z, Dirichlet faces on
+ * [0,1]^3, rhs = -(12 pi^2 + lambda) sin(pi x) sin(pi y) sin(pi z) -- through the constant-
+ * coefficient overload of the solver (BICGStab3D/solveLin_BICGStab.C:200-215), solved to 1e-6
+ * and compared with the analytic solution sin(pi x) sin(pi y) sin(pi z).
+ * (With lambda = 0 and D = (1,1,1) the right-hand side is an eigenvector of the discrete
+ * operator: the first BiCG step is exact and BiCGStab(2) then breaks down with alpha = 0/0,
+ * in the reference as here.)
  *
  *   gcc -std=c99 -O2 -Iinclude examples/solve_poisson.c -Lkrylov_amd -lkrylov_amd -lm \
  *       -Wl,-rpath,$PWD/krylov_amd -o examples/solve_poisson && examples/solve_poisson [N] [L]
@@ -35,8 +38,9 @@ int main(int argc, char **argv)
 		for (j = 0; j <= n; ++j)
 			for (i = 0; i <= n; ++i) {
 				const double x = (double)i / n, y = (double)j / n, z = (double)k / n;
-				rhs[((size_t)(k + 1) * w + (j + 1)) * w + (i + 1)] =
-				    -3. * M_PI * M_PI * sin(M_PI * x) * sin(M_PI * y) * sin(M_PI * z);
+				const size_t p = ((size_t)(k + 1) * w + (j + 1)) * w + (i + 1);
+				lam[p] = 0.2 * x * y * y * z;
+				rhs[p] = -(12. * M_PI * M_PI + lam[p]) * sin(M_PI * x) * sin(M_PI * y) * sin(M_PI * z);
 			}
 
 	memset(&d, 0, sizeof d);
@@ -49,7 +53,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "kry_create: %s (%s)\n", kry_status_string(status), kry_last_error());
 		return 1;
 	}
-	status = kry_solve_const(h, phi, rhs, lam, 1., 1., 1., 0);
+	status = kry_solve_const(h, phi, rhs, lam, 1., 1., 10., 0);
 	kry_get_stats(h, &st);
 	kry_destroy(h);
 	if (status != KRY_OK) {

@@ -193,9 +193,9 @@ def test_driver_writes_field_file_and_restarts_from_it(tmp_path):
     assert float(re.search(r"l2 error for 32 is (\S+)", again.stdout).group(1)) == err
 
 
-def test_plain_c_caller_solves_the_64_cubed_poisson_problem():
-    """examples/solve_poisson.c (C99, C ABI only): the 64^3 Dirichlet Poisson problem of the reference's
-    plumbing configuration, l = 2 and l = 1; second-order l2 error against the analytic solution."""
+def test_plain_c_caller_solves_the_reference_drivers_first_test():
+    """examples/solve_poisson.c (C99, C ABI only): test 1 of the reference's driver at 64^3, l = 2 and
+    l = 1; second-order l2 error against the analytic solution."""
     exe = os.path.join(ROOT, "examples", "solve_poisson")
     if not os.path.exists(exe):
         pytest.skip("examples not built")
@@ -203,6 +203,5 @@ def test_plain_c_caller_solves_the_64_cubed_poisson_problem():
         out = subprocess.run([exe, "64", str(L)], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         m = re.search(r"passes (\d+) .* l2 error (\S+)  kernels (\w+)", out.stdout)
-        # (this right-hand side is an eigenvector of the discrete operator: one pass suffices)
-        assert m and 1 <= int(m.group(1)) < 200 and m.group(3) == "fused"
+        assert m and 3 < int(m.group(1)) < 300 and m.group(3) == "fused"
         assert 0.5e-4 < float(m.group(2)) < 3e-4          # (pi h)^2 / 12 * O(1) at h = 1/64
