@@ -146,7 +146,7 @@ def test_mapped_memory_exchange_reproduces_the_transport(tmp_path, monkeypatch, 
 
 
 @gpu
-@pytest.mark.parametrize("world,kind,nproc", [(4, "var", None), (8, "var", (2, 2, 2))])
+@pytest.mark.parametrize("world,kind,nproc", [(4, "var", None), (4, "var", (2, 2, 1))])
 def test_mapped_memory_exchange_over_many_passes(tmp_path, monkeypatch, world, kind, nproc):
     """150 passes (900 all-reduces, 600 and more plane exchanges per rank, slots and sequence words
     reused throughout): still the transport's history, bit for bit."""
