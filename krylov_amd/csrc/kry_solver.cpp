@@ -1463,6 +1463,9 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		// faces, interface planes and general faces are not; equal on all slabs of a split)
 		const int nz = (h->gen || h->np[2] > 1) ? g.mz + 1 : g.mz - 1;
 		h->zc = std::min(64, std::max(g.mz <= 64 ? 2 : 4, (nz + chunks - 1) / chunks));
+		// even chunks: no short last chunk that pays the full three-plane prologue for a plane or two
+		const int nch = (nz + h->zc - 1) / h->zc;
+		h->zc = (nz + nch - 1) / nch;
 	}
 	if (st < 0) {
 		kry_destroy(h);
