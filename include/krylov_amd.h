@@ -199,6 +199,11 @@ int kry_load_var(kry_handle h, const double *phi, const double *rhs, const doubl
 int kry_iterate(kry_handle h, int n_outer);
 int kry_fetch_phi(kry_handle h, double *phi);
 
+/* Per-kernel timing (HIP events around every launch of the fused path, accumulated in
+ * kry_stats.kernel_ms / kernel_calls) on or off from the next kry_iterate on; the start value
+ * comes from KRY_PROFILE.  A measurement aid without counterpart in the reference. */
+int kry_set_profile(kry_handle h, int on);
+
 int kry_get_stats(kry_handle h, kry_stats *out);
 /* `norm` of every outer iteration (solveLin_BICGStab.C:464); returns the count. */
 int kry_get_history(kry_handle h, double *norms, int cap);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks", "kry_device_check",
     "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
-    "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
+    "kry_set_profile", "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
 ]
 
@@ -122,6 +122,8 @@ def lib():
     L.kry_iterate.argtypes = [vp, ci]
     L.kry_fetch_phi.restype = ci
     L.kry_fetch_phi.argtypes = [vp, _dp]
+    L.kry_set_profile.restype = ci
+    L.kry_set_profile.argtypes = [vp, ci]
     L.kry_get_stats.restype = ci
     L.kry_get_stats.argtypes = [vp, P(KryStats)]
     L.kry_get_history.restype = ci
@@ -242,6 +244,9 @@ class Solver:
         self._cbs = (ALLREDUCE_CB(ar), HALO_CB(hl))      # keep alive
         _check(lib().kry_comm_init_callbacks(self._h, rank, nranks, self._cbs[0], self._cbs[1], None),
                "kry_comm_init_callbacks")
+
+    def set_profile(self, on):
+        _check(lib().kry_set_profile(self._h, int(bool(on))), "kry_set_profile")
 
     def mail_export(self):
         """This rank's mailbox handle (bytes) for the device-side all-reduce."""

@@ -1707,6 +1707,15 @@ int kry_mail_enable(kry_handle h, int on)
 	return KRY_OK;
 }
 
+int kry_set_profile(kry_handle h, int on)
+{
+	if (!h) { set_err("null argument"); return KRY_ERR_ARG; }
+	CHK(sync_all(h));
+	drop_graph(h);
+	h->profile = on != 0;
+	return KRY_OK;
+}
+
 int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda, double Dxx,
                    double Dyy, double Dzz)
 {
