@@ -356,7 +356,7 @@ def main():
     # Several GPUs: the timed region runs without per-kernel events (rank 0 would lag behind the
     # others by their cost); the kernel table and the roofline come from a few extra passes.
     probe = 0
-    if world > 1 and ok:
+    if world > 1 and all_ok(ok):          # (a collective decision: every rank runs the extra passes or none)
         try:
             solver.set_profile(True)
             k_ms0, k_n0 = list(s1.kernel_ms), list(s1.kernel_calls)
