@@ -8,6 +8,13 @@
 //
 //   bicgstab [-n MX] [-t 1..5] [-r] [-l L] [-e TOL] [-i MAXITER] [--stats] [-q]
 //
+// The spellings of the OpenCL driver are understood as well (--np, -p/--precision, --random,
+// -s/--stats/--statistical, -v/--verbose, and --gpu/--cpu/--acc, which choose an OpenCL context
+// there and are accepted without effect here: the device is a HIP GPU, KRY_DEVICES picks it),
+// so that its sweep script (BiCGStab3D_CL/statistics.sh: `--gpu --stats -t T -n N` over a list
+// of sizes, rows appended to one file) runs against this binary; --stats prints the same
+// tab-separated row under the same header (BiCGStab3D_CL/main.cpp:576, 599-602).
+//
 // Built with -D parallel (and an MPI installation) it is the reference's parallel
 // driver: `mpiexec -n P bicgstab_mpi ...` splits the domain over P processes, one GPU
 // each (KRY_DEVICES lists the devices, default all on 0): 2 x 2 x 2 for P = 8 as the
@@ -75,7 +82,7 @@ void usage(const char *argv0)
 	cout << "    -e   --tolerance TOL          Relative tolerance, default 1e-6" << endl;
 	cout << "    -i   --iterations N           Stop after N outer iterations" << endl;
 	cout << "    -s   --seed SEED              Seed for --randomize" << endl;
-	cout << "         --stats                  Print one CSV row instead of the report" << endl;
+	cout << "         --stats                  Print one tab-separated row instead of the report" << endl;
 	cout << "    -q   --quiet                  No per-iteration output" << endl;
 #ifdef WITH_HDF5
 	cout << "    -o   --output FILE            Write phi, phi_ana and rhs to an HDF5 field file" << endl;
@@ -92,8 +99,14 @@ bool parse(int argc, char **argv, Options &o)
 			return argv[++i];
 		};
 		if (a == "-h" || a == "--help") { usage(argv[0]); exit(EXIT_SUCCESS); }
-		else if (a == "-n" || a == "--size" || a == "--mx") o.mx = atoi(need("Size"));
-		else if (a == "-r" || a == "--randomize") o.randomize = true;
+		else if (a == "-n" || a == "--size" || a == "--mx" || a == "--np") o.mx = atoi(need("Size"));
+		else if (a == "-r" || a == "--randomize" || a == "--random") o.randomize = true;
+		else if (a == "--gpu" || a == "--cpu" || a == "--acc" || a == "--accelerator") {}   // OpenCL context choices
+		else if (a == "-v" || a == "--verbose") o.quiet = false;
+		else if (a == "-p" || a == "--precision") o.tol = atof(need("Tolerance"));
+		else if (a == "--statistical") o.stats = true;
+		// -s: the seed when a number follows, else the OpenCL driver's short form of --stats
+		else if (a == "-s" && (i >= argc - 1 || argv[i + 1][0] == '-')) o.stats = true;
 		else if (a == "-t" || a == "--test") {
 			o.test = atoi(need("Test"));
 			if (o.test < 1 || o.test > 5) { cerr << "Illegal test number. Must be [1-5] " << endl; return false; }
@@ -321,10 +334,11 @@ int main(int argc, char *argv[])
 			avg = sum / steps.size();
 			geo = exp(logsum / steps.size());
 		}
-		cout << "# Test, Size, Iterations, Total runtime, Calculation time, Min step time, Max step time, "
-		        "Average (arithmetic), Average (geometric), Tolerance, L2 error, Max error" << endl;
-		printf("%d, %d, %d, %.3f, %.3f, %.4f, %.4f, %.4f, %.4f, %g, %.6e, %.6e\n", opt.test, opt.mx, it, runtime, calc, tmin,
-		       tmax, avg, geo, opt.tol, l2err, emax);
+		cout << "# Test\tSize\tIterations\tTotal runtime\tCalculation time\tMin step time\tMax step time\t"
+		        "Average (arithmetic)\tAverage (geometric)\tTolerance\tL2 error\tMax error" << endl;
+		const char sep = '\t';
+		cout << opt.test << sep << opt.mx << sep << it << sep << runtime << sep << calc << sep << tmin << sep << tmax << sep
+		     << avg << sep << geo << sep << opt.tol << sep << l2err << sep << emax << endl;
 	} else {
 		cout << " l2 error for " << opt.mx << " is " << l2err << endl;
 		cout << "Runtime (solver) : " << (long long)runtime << " ms" << endl;

@@ -92,8 +92,19 @@ def test_driver_stats_row():
     out = subprocess.run([DRIVER, "-n", "24", "-t", "2", "--stats"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     rows = [l for l in out.stdout.splitlines() if l and not l.startswith("#")]
-    cols = rows[-1].split(",")
+    cols = rows[-1].split("\t")
     assert len(cols) == 12 and int(cols[0]) == 2 and int(cols[1]) == 24 and int(cols[2]) > 0
+    head = [l for l in out.stdout.splitlines() if l.startswith("#")][-1]
+    assert head.split("\t") == ["# Test", "Size", "Iterations", "Total runtime", "Calculation time", "Min step time",
+                                "Max step time", "Average (arithmetic)", "Average (geometric)", "Tolerance", "L2 error",
+                                "Max error"]                      # BiCGStab3D_CL/main.cpp:576
+    # the call of the reference's sweep script (BiCGStab3D_CL/statistics.sh), on one of its sizes
+    sweep = subprocess.run([DRIVER, "--gpu", "--stats", "-t", "3", "-n", "84"], capture_output=True, text=True, timeout=120)
+    assert sweep.returncode == 0, sweep.stdout + sweep.stderr
+    row = [l for l in sweep.stdout.splitlines() if l and not l.startswith("#")][-1].split("\t")
+    assert len(row) == 12 and int(row[0]) == 3 and int(row[1]) == 84 and float(row[10]) < 1e-3
+    short = subprocess.run([DRIVER, "-s", "-p", "1e-5", "--np", "24"], capture_output=True, text=True, timeout=120)
+    assert short.returncode == 0 and float(short.stdout.splitlines()[-1].split("\t")[9]) == 1e-5
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
