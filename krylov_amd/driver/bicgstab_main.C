@@ -218,7 +218,9 @@ int main(int argc, char *argv[])
 					                  A * sqr(x) * z * pi * cx * sy * sz;
 					break;
 				}
-				case 4: { // rotated anisotropic tensor (main.C:360-394)
+				case 4: { // rotated anisotropic tensor (main.C:360-394).  As there, the right-hand side is 0/0 on
+				          // the edge x = y = 0 (r2 below): its norm is NaN, the stopping test `norm > eps*normRHS`
+				          // is false at once and the run ends after one pass with phi near zero.
 					const double ang = atan2(y, x), sa = sin(ang), ca = cos(ang);
 					const double dxx = dfac[0] * (DPar * sqr(sa) + DPerp * sqr(ca));
 					const double dyy = dfac[1] * (DPar * sqr(ca) + DPerp * sqr(sa));
