@@ -222,7 +222,10 @@ int kry_get_step_times(kry_handle h, double *ms, int cap);
  *   kry_op_dot      : Krylov::dot_product                   BICGStab3D/Krylov.C:161-244
  *   kry_op_l2norm   : Krylov::get_l2Norm                    BICGStab3D/Krylov.C:36-157
  * `fused` selects the LDS-tiled Dirichlet kernel (requires all faces Dirichlet)
- * instead of the generic one. */
+ * instead of the generic one.
+ * They borrow the handle's fields: a problem loaded with kry_load_* is gone
+ * afterwards (kry_iterate / kry_fetch_phi then return KRY_ERR_STATE until the
+ * next load or solve). */
 int kry_op_do_bcs(kry_handle h, double *field);
 int kry_op_spmv_const(kry_handle h, double *psi, const double *lambda, double Dxx, double Dyy,
                       double Dzz, double *out, int apply_bcs, int fused);

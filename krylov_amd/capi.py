@@ -83,7 +83,9 @@ _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
 def lib():
-    """Load the shared library (no device is touched by loading)."""
+    """Load the shared library.  Loading runs the library's constructor, which
+    initialises its HIP runtime (a device count query): the first copy of the runtime
+    that touches the GPU in a process must be this one."""
     global _lib
     if _lib is not None:
         return _lib
@@ -104,6 +106,12 @@ def lib():
     L.kry_comm_selftest.argtypes = [ci]
     L.kry_comm_init_callbacks.restype = ci
     L.kry_comm_init_callbacks.argtypes = [vp, ci, ci, ALLREDUCE_CB, HALO_CB, vp]
+    L.kry_comm_init_host_callbacks.restype = ci
+    L.kry_comm_init_host_callbacks.argtypes = [vp, ci, ci, ALLREDUCE_CB, HALO_CB, vp]
+    L.kry_device_check.restype = ci
+    L.kry_device_check.argtypes = [ci]
+    L.kry_get_step_times.restype = ci
+    L.kry_get_step_times.argtypes = [vp, vp, ci]
     L.kry_mail_export.restype = ci
     L.kry_mail_export.argtypes = [vp, vp]
     L.kry_mail_connect.restype = ci
@@ -296,6 +304,12 @@ class Solver:
     def history(self, cap=65536):
         buf = np.zeros(cap, dtype=np.float64)
         n = _check(lib().kry_get_history(self._h, _ptr(buf), cap), "kry_get_history")
+        return buf[:min(n, cap)].copy()
+
+    def step_times(self, cap=65536):
+        """Wall-clock milliseconds of every outer iteration since the last load."""
+        buf = np.zeros(cap, dtype=np.float64)
+        n = _check(lib().kry_get_step_times(self._h, _ptr(buf), cap), "kry_get_step_times")
         return buf[:min(n, cap)].copy()
 
     # single operators ------------------------------------------------------

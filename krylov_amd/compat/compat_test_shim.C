@@ -77,6 +77,29 @@ int compat_solve(const int mx[3], const int bc[6], int L, double eps, int max_it
 	return s.iterations();
 }
 
+// the three-field overload (BICGStab3D/solveLin_BICGStab.C:238-248); Dzz is copied back so
+// that the caller sees what the solver did to it; quirk != 0: the reference's behaviour
+int compat_solve3(const int mx[3], int L, double eps, double *phi, const double *rhs, const double *lam, const double *Dxx,
+                  const double *Dyy, double *Dzz, int quirk)
+{
+	grid_1D gx(0, 1, mx[0] + 1, 2, 0, true), gy(0, 1, mx[1] + 1, 2, 0, true), gz(0, 1, mx[2] + 1, 2, 0, true);
+	BoundaryHandler3D b;
+	b.set_bcType(0);
+	NumMatrix<double, 3> mphi, mrhs, mlam, mDxx, mDyy, mDzz;
+	wrap(mphi, mx, phi); wrap(mrhs, mx, rhs); wrap(mlam, mx, lam);
+	wrap(mDxx, mx, Dxx); wrap(mDyy, mx, Dyy); wrap(mDzz, mx, Dzz);
+	BICGStab s;
+	s.set_ReferenceThreeFieldQuirk(quirk != 0);
+	Linsolver3D *ls = &s;
+	NumArray<int> pars(1);
+	pars(0) = L;
+	ls->setup(gx, gy, gz, eps, pars, true, false, 0);
+	ls->solve(b, mphi, mrhs, mlam, mDxx, mDyy, mDzz, 0);
+	memcpy(phi, mphi.data(), mphi.size() * sizeof(double));
+	memcpy(Dzz, mDzz.data(), mDzz.size() * sizeof(double));
+	return s.iterations();
+}
+
 // the construction style of the reference's OpenCL solver (BiCGStab3D_CL/main.cpp:410-412, 532-540):
 // constant-coefficient solve on Dirichlet faces; out = {iterations, steptimeMin, steptimeMax, number of step times,
 // sum of the unrounded step times in ms}

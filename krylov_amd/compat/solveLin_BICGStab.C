@@ -281,7 +281,11 @@ void BICGStab::solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMa
 	// The reference forwards Dzz in the place of Dxy, which the four-field
 	// overload then clears (BICGStab3D/solveLin_BICGStab.C:238-248, 231-233): the
 	// caller's Dzz is zeroed before the solve.  Here the off-diagonal element is
-	// simply absent and Dzz is left intact.
+	// simply absent and Dzz is left intact, unless the reference's behaviour was asked for.
+	if (three_field_quirk) {
+		solve(bounds, phi, rhs, lambda, Dxx, Dyy, Dzz, Dzz, debug_, false);
+		return;
+	}
 	use_spatialDiffusion = true;
 	debug = debug_;
 	use_offDiagDiffusion = false;

@@ -213,7 +213,7 @@ int KryComm::halo(int peer_lo, const double *send_lo, double *recv_lo, int peer_
 		char *plo = peer_lo >= 0 ? link_peer_[peer_lo] : nullptr, *phi = peer_hi >= 0 ? link_peer_[peer_hi] : nullptr;
 		if (kry_launch_halo_push(plo ? send_lo : nullptr, plo ? slot(plo, 1) : nullptr, plo ? flag(plo, 1) : nullptr,
 		                         phi ? send_hi : nullptr, phi ? slot(phi, 0) : nullptr, phi ? flag(phi, 0) : nullptr, count,
-		                         seq, link_ticket_, st) != hipSuccess ||
+		                         seq, link_ticket_, link_S_, st) != hipSuccess ||
 		    kry_launch_halo_pull(plo ? recv_lo : nullptr, plo ? slot(link_self_, 0) : nullptr, flag(link_self_, 0),
 		                         phi ? recv_hi : nullptr, phi ? slot(link_self_, 1) : nullptr, flag(link_self_, 1), count,
 		                         seq, link_timeout_, link_S_, st) != hipSuccess) {

@@ -76,7 +76,7 @@ hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int 
 hipError_t kry_launch_face(double *field, double *buf, const KryGeo &g, int dir, int idx, bool to_buf, hipStream_t st);
 hipError_t kry_launch_halo_push(const double *send_lo, double *slot_lo, unsigned long long *flag_lo, const double *send_hi,
                                 double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
-                                unsigned *ticket, hipStream_t st);
+                                unsigned *ticket, const KryState *S, hipStream_t st);
 hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned long long *flag_lo, double *recv_hi,
                                 const double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
                                 long long timeout, KryState *S, hipStream_t st);

@@ -1038,8 +1038,10 @@ __device__ inline void halo_copy(const KryHaloSide &sd, size_t count)
 }
 
 __global__ __launch_bounds__(NT) void k_halo_push(KryHaloSide lo, KryHaloSide hi, size_t count, unsigned long long seq,
-                                                  unsigned *ticket)
+                                                  unsigned *ticket, const KryState *S)
 {
+	// an earlier exchange of this solve gave up on a neighbour: nothing more is sent
+	if (S && S->done && S->status < 0) return;
 	if (lo.src) halo_copy(lo, count);
 	if (hi.src) halo_copy(hi, count);
 	__threadfence_system();          // this thread's stores have reached the neighbour's memory
@@ -1059,7 +1061,9 @@ __global__ __launch_bounds__(NT) void k_halo_pull(KryHaloSide lo, KryHaloSide hi
 {
 	__shared__ int failed;
 	if (threadIdx.x == 0) {
-		int bad = 0;
+		// a solve that has already failed (an earlier exchange timed out) does not wait again:
+		// every exchange still queued behind the failure returns at once
+		int bad = (S->done && S->status < 0) ? 1 : 0;
 		const long long t0 = wall_clock64();
 		unsigned spins = 0;
 		for (int side = 0; side < 2 && !bad; ++side) {
@@ -1362,11 +1366,11 @@ hipError_t kry_launch_repack(double *dev, double *packed, int w, long rows, int 
 
 hipError_t kry_launch_halo_push(const double *send_lo, double *slot_lo, unsigned long long *flag_lo, const double *send_hi,
                                 double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
-                                unsigned *ticket, hipStream_t st)
+                                unsigned *ticket, const KryState *S, hipStream_t st)
 {
 	KryHaloSide lo = {send_lo, slot_lo, flag_lo}, hi = {send_hi, slot_hi, flag_hi};
 	const int nb = (int)std::max<size_t>(1, std::min<size_t>((count / 2 + NT - 1) / NT, 256));
-	hipLaunchKernelGGL(k_halo_push, dim3(nb), dim3(NT), 0, st, lo, hi, count, seq, ticket);
+	hipLaunchKernelGGL(k_halo_push, dim3(nb), dim3(NT), 0, st, lo, hi, count, seq, ticket, S);
 	return hipGetLastError();
 }
 

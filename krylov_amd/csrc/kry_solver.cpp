@@ -70,6 +70,7 @@ struct Slab {
 	hipEvent_t ev_in = nullptr;
 	hipEvent_t ev_edge = nullptr;    // the outermost chunks of a stencil kernel are done
 	hipEvent_t ev_halo = nullptr;    // this slab's ghost planes are filled
+	hipEvent_t ev_read = nullptr;    // this slab's copies out of its neighbours' planes are queued
 	KryGeo g;
 	long guard = 0;
 	Field phi, rhs, lam, Dxx, Dyy, Dzz, Dxy, rt, tmp;
@@ -391,6 +392,19 @@ int exchange_halo(kry_solver *h, std::vector<double *> &f)
 		HIPCHK(hipStreamWaitEvent(lo.st, hi.ev, 0));
 		HIPCHK(hipMemcpyAsync(f[i] + (long)(g.mz + 1 + 1) * g.ps, f[i + 1] + (long)(1 + 1) * g.ps, bytes,
 		                      hipMemcpyDeviceToDevice, lo.st));
+	}
+	if (ns > 1) {
+		// a slab may go on (and update the copied planes in place) only when its neighbours have
+		// read them: every stream waits for the copies queued on the neighbouring streams
+		for (int i = 0; i < ns; ++i) {
+			HIPCHK(hipSetDevice(h->slabs[i].device));
+			HIPCHK(hipEventRecord(h->slabs[i].ev_read, h->slabs[i].st));
+		}
+		for (int i = 0; i < ns; ++i) {
+			HIPCHK(hipSetDevice(h->slabs[i].device));
+			if (i > 0) HIPCHK(hipStreamWaitEvent(h->slabs[i].st, h->slabs[i - 1].ev_read, 0));
+			if (i + 1 < ns) HIPCHK(hipStreamWaitEvent(h->slabs[i].st, h->slabs[i + 1].ev_read, 0));
+		}
 	}
 	if (h->comm.active()) {
 		// with RCCL a process owns exactly one slab (checked in kry_comm_init)
@@ -1429,6 +1443,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			HIPCHK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
 			HIPCHK(hipEventCreateWithFlags(&s.ev_edge, hipEventDisableTiming));
 			HIPCHK(hipEventCreateWithFlags(&s.ev_halo, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&s.ev_read, hipEventDisableTiming));
 			KryGeo &g = s.g;
 			g.mx = d->mx[0]; g.my = d->mx[1]; g.mz = h->mzl;
 			g.px = ((g.mx + 4 + 15) / 16) * 16;
@@ -1439,7 +1454,10 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			for (int k = 0; k < 2; ++k) { g.nb[2 * k] = h->co[k] > 0; g.nb[2 * k + 1] = h->co[k] < h->np[k] - 1; }
 			g.nb[4] = g.has_lo; g.nb[5] = g.has_hi;
 			for (int f = 0; f < 6; ++f) g.bc[f] = d->bc_type[f];
-			s.guard = 20L * g.px + 256;
+			// guard zones: tile overshoot and halo reads of the stencil kernels (a few rows), and the
+			// streaming kernels, whose blocks load whole KRY_SEG-double segments past the end of the
+			// last plane they touch before masking the stores
+			s.guard = std::max<long>(20L * g.px + 256, KRY_SEG + 64);
 			CHK(alloc_field(s, s.phi));
 			CHK(alloc_field(s, s.rhs));
 			CHK(alloc_field(s, s.lam));
@@ -1535,6 +1553,7 @@ void kry_destroy(kry_handle h)
 		if (s.ev_in) hipEventDestroy(s.ev_in);
 		if (s.ev_edge) hipEventDestroy(s.ev_edge);
 		if (s.ev_halo) hipEventDestroy(s.ev_halo);
+		if (s.ev_read) hipEventDestroy(s.ev_read);
 		if (s.st_comm) hipStreamDestroy(s.st_comm);
 		if (s.st) hipStreamDestroy(s.st);
 	}
@@ -1843,6 +1862,10 @@ int kry_get_step_times(kry_handle h, double *ms, int cap)
 
 static int op_prepare(kry_handle h, bool var, bool offd, const double Dc[3])
 {
+	// the single operators borrow the solver's fields (phi, rhs, lam, r0) and its operator
+	// description: whatever problem was loaded is gone
+	h->loaded = false;
+	drop_graph(h);
 	h->gen = false;
 	h->var = var;
 	h->offd = var && offd;
@@ -1853,6 +1876,7 @@ static int op_prepare(kry_handle h, bool var, bool offd, const double Dc[3])
 int kry_op_do_bcs(kry_handle h, double *field)
 {
 	if (!h || !field) return KRY_ERR_ARG;
+	h->loaded = false;      // phi is overwritten
 	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(upload(h, h->slabs[i], (int)i, h->slabs[i].phi, field));
 	CHK(g_do_bcs(h, &Slab::phi));
 	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(download(h, h->slabs[i], (int)i, h->slabs[i].phi, field));
@@ -1921,6 +1945,7 @@ int kry_op_spmv_var(kry_handle h, const double *psi, const double *lambda, const
 
 static int op_dot(kry_handle h, const double *a, const double *b, int norm_mode, double *result)
 {
+	h->loaded = false;      // phi and rhs are overwritten
 	for (size_t i = 0; i < h->slabs.size(); ++i) {
 		Slab &s = h->slabs[i];
 		CHK(upload(h, s, (int)i, s.phi, a));

@@ -62,6 +62,22 @@ def main():
             s.mail_connect(rank, world, handles)
             if os.environ.get("KRY_TEST_NO_TRANSPORT") != "1":
                 s.mail_enable(mail)
+        if os.environ.get("KRY_TEST_MAIL_ABSENT") == "2":  # the last rank vanishes after the load: every exchange of the
+            import time                                     # batch of passes queued behind it finds no partner
+            s.load_var(loc.phi.copy(), loc.rhs, loc.lam, loc.Dxx, loc.Dyy, loc.Dzz, loc.Dxy, loc.use_offdiag)
+            dist.barrier()
+            if rank == world - 1:
+                time.sleep(6.0)                              # (its mailbox stays mapped meanwhile)
+                os._exit(0)
+            t0 = time.time()
+            try:
+                s.iterate(8)
+                msg = "no error"
+            except capi.KryError as e:
+                msg = str(e)
+            with open(os.path.join(outdir, "r%d.err" % rank), "w") as f:
+                f.write("%.3f s: %s" % (time.time() - t0, msg))
+            os._exit(0)
         if os.environ.get("KRY_TEST_MAIL_ABSENT") == "1":  # the last rank never shows up at the first dot product
             import time
             if rank == world - 1:

@@ -154,7 +154,7 @@ def test_general_boundary_fused_path_matches_oracle_in_device_order(orc, bc, L):
 
 
 @pytest.mark.parametrize("L", [1, 2])
-@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9)])
+@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9), (16, 62, 16)])
 def test_general_boundary_fused_path_ragged_shapes(orc, n, L):
     """Tile edges that fall inside the ghost layer, several tiles per row, short chunks."""
     bc = (1, 1, 0, 1, 1, 1)

@@ -48,6 +48,32 @@ def test_adaptor_class_equals_c_abi(maker, L):
     assert np.array_equal(a["phi"], b["phi"])
 
 
+def test_three_field_overload(orc):
+    """solve(bounds, phi, rhs, lambda, Dxx, Dyy, Dzz): by default the solve of the four-field
+    overload without off-diagonal term, Dzz left intact; with the reference's quirk switched on
+    (BICGStab3D/solveLin_BICGStab.C:238-248 forwards Dzz as Dxy, which :231-233 clears) the
+    caller's Dzz comes back zeroed and the solve is the one with Dzz = 0, as the oracle's."""
+    capi.lib()
+    S = C.CDLL(LIB)
+    i3 = C.c_int * 3
+    S.compat_solve3.restype = C.c_int
+    S.compat_solve3.argtypes = [i3, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int]
+    p = P.smooth_var(24)
+    phi, dzz = p.phi.copy(), p.Dzz.copy()
+    n = S.compat_solve3(i3(*p.mx), 2, 1e-8, phi, p.rhs.copy(), p.lam.copy(), p.Dxx.copy(), p.Dyy.copy(), dzz, 0)
+    want = capi.solve_problem(p, L=2, eps=1e-8)
+    assert n == want["iters"] and np.array_equal(phi, want["phi"]) and np.array_equal(dzz, p.Dzz)
+    phi, dzz = p.phi.copy(), p.Dzz.copy()
+    n = S.compat_solve3(i3(*p.mx), 2, 1e-8, phi, p.rhs.copy(), p.lam.copy(), p.Dxx.copy(), p.Dyy.copy(), dzz, 1)
+    assert not dzz.any()
+    q = P.smooth_var(24)
+    q.Dzz[:] = 0.
+    want = capi.solve_problem(q, L=2, eps=1e-8)
+    assert n == want["iters"] and np.array_equal(phi, want["phi"])
+    ref = oracle_solve(orc, q, L=2, eps=1e-8)
+    assert np.linalg.norm(points(phi) - points(ref["phi"])) <= 1e-6 * np.linalg.norm(points(ref["phi"]))
+
+
 def test_adaptor_mixed_faces():
     """Field coefficients with extrapolating faces: the fused general-boundary
     kernels; constant coefficients: one kernel per primitive."""

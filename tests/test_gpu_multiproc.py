@@ -200,6 +200,30 @@ def test_mailbox_allreduce_gives_up_on_an_absent_rank(tmp_path, monkeypatch):
 
 
 @gpu
+def test_mapped_memory_planes_give_up_once(tmp_path, monkeypatch):
+    """Ghost planes through mapped memory, the neighbour gone after the load: the first exchange of
+    the batch of passes waits KRY_MAIL_TIMEOUT_MS and fails the solve, and the dozens of exchanges
+    queued behind it return at once instead of waiting that long each."""
+    monkeypatch.setenv("KRY_TEST_MAIL", "3")
+    monkeypatch.setenv("KRY_TEST_NO_TRANSPORT", "1")
+    monkeypatch.setenv("KRY_TEST_MAIL_ABSENT", "2")
+    monkeypatch.setenv("KRY_MAIL_TIMEOUT_MS", "500")
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_slab_worker.py"), str(r), "2", str(port), "var", "2",
+                               "0", "1e-30", str(tmp_path)]) for r in range(2)]
+    try:
+        codes = [q.wait(timeout=120) for q in procs]
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    assert codes == [0, 0]
+    msg = (tmp_path / "r0.err").read_text()
+    assert "communication error" in msg, msg
+    assert float(msg.split(" s:")[0]) < 3.0, msg       # 8 passes x 4 exchanges would take 16 s
+
+
+@gpu
 def test_processes_full_solve(tmp_path):
     from krylov_amd import capi
     p = make_problem("var")
