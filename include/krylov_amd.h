@@ -235,6 +235,24 @@ int kry_op_spmv_var(kry_handle h, const double *psi, const double *lambda, const
 int kry_op_dot(kry_handle h, const double *a, const double *b, double *result);
 int kry_op_l2norm(kry_handle h, const double *v, double *result);
 
+/* kry_op_dot / kry_op_l2norm for callers that cannot allocate.  No counterpart in the
+ * reference: it is for code under HIP graph capture, tight serving loops and harnesses
+ * that forbid hipMalloc.  The same weighted sum (Krylov::dot_product, or with norm_mode
+ * != 0 Krylov::get_l2Norm of a == b) by the same kernel in the same summation order, but
+ *   - a and b are DEVICE pointers to fields in the host layout described at the top
+ *     (ghost-inclusive, x fastest, no padding) with last grid-point indices mx[3];
+ *   - the result (one double) is written to the DEVICE pointer `result`;
+ *   - everything is queued on `stream` (a hipStream_t, NULL = the default stream) of
+ *     HIP device `device`; the call neither synchronises nor allocates: the kernel's
+ *     partial sums and ticket live in a file-scope device array of about 33 KB that
+ *     every GPU the library runs on holds until the process ends.
+ * Fields of more than KRY_STATIC_DOT_MAX_DOUBLES doubles (ghosts included) are refused
+ * with KRY_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in
+ * time on one GPU (different streams, or threads) race; calls ordered on one stream do not. */
+#define KRY_STATIC_DOT_MAX_DOUBLES 2147483648L
+int kry_op_dot_static(int device, const double *a, const double *b, const int mx[3], int norm_mode,
+                      double *result, void *stream);
+
 const char *kry_status_string(int status);
 const char *kry_last_error(void);
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
     "kry_set_profile", "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
-    "kry_op_dot", "kry_op_l2norm", "kry_status_string", "kry_last_error",
+    "kry_op_dot", "kry_op_l2norm", "kry_op_dot_static", "kry_status_string", "kry_last_error",
 ]
 
 
@@ -146,6 +146,8 @@ def lib():
     L.kry_op_dot.argtypes = [vp, _dp, _dp, P(cd)]
     L.kry_op_l2norm.restype = ci
     L.kry_op_l2norm.argtypes = [vp, _dp, P(cd)]
+    L.kry_op_dot_static.restype = ci
+    L.kry_op_dot_static.argtypes = [ci, vp, vp, C.c_int * 3, ci, vp, vp]
     L.kry_status_string.restype = C.c_char_p
     L.kry_status_string.argtypes = [ci]
     L.kry_last_error.restype = C.c_char_p

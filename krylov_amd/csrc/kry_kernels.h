@@ -27,6 +27,8 @@ struct KryRed {
 	KryState *S;
 	int nblk;
 	int phase;           // KryPhase run by the last block when S->local_scalars
+	double *out;         // S == nullptr: the sums go here instead of S->sums (no recurrences, no mailboxes)
+	int out_sqrt;        //   ... as their square roots
 };
 
 struct KryFused {
@@ -87,3 +89,7 @@ hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool off
                             const double *Dxy, double *out, hipStream_t st);
 hipError_t kry_launch_wdot(const KryGeo &g, const double *x, const double *y, int norm_mode, KryRed red,
                            hipStream_t st);
+// The weighted dot with its partial sums and ticket in a file-scope device array instead of
+// allocated memory (see kry_op_dot_static in include/krylov_amd.h).
+hipError_t kry_launch_wdot_static(int device, const KryGeo &g, const double *x, const double *y, int norm_mode,
+                                  double *result, hipStream_t st);

@@ -270,20 +270,21 @@ __device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, i
 		if (lane == 0) red[w][k] = v;
 	}
 	__syncthreads();
-	if (r.S->mail) {
+	if (r.S && r.S->mail) {
 		mail_allreduce<ND>(red, r);
 		return;
 	}
 	if (tid == 0) {
+		double *dst = r.S ? r.S->sums : r.out;
 #pragma unroll
 		for (int k = 0; k < ND; ++k) {
 			double v = red[0][k];
 #pragma unroll
 			for (int i = 1; i < NW; ++i) v += red[i][k];
-			r.S->sums[k] = v;
+			dst[k] = (!r.S && r.out_sqrt) ? sqrt(v) : v;
 		}
 		__hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (r.S->local_scalars && r.phase != PH_NONE) kry_scalar_step(r.S, r.phase);
+		if (r.S && r.S->local_scalars && r.phase != PH_NONE) kry_scalar_step(r.S, r.phase);
 	}
 }
 
@@ -1419,6 +1420,47 @@ hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool off
 	else if (!offd) { if (ex) KRY_G(true, false, true); else KRY_G(true, false, false); }
 	else { if (ex) KRY_G(true, true, true); else KRY_G(true, true, false); }
 #undef KRY_G
+	return hipGetLastError();
+}
+
+// Scratch of the allocation-free weighted dot: one partial sum per block of the largest grid
+// g_wdot is ever launched with, then a 256-byte cell holding the ticket counter.  Every GPU
+// holds its own copy of the array until the process ends (about 33 KB).  In host code the
+// array's name is only a handle for hipGetSymbolAddress: kernels get the per-device address.
+#define KRY_STATIC_PARTIALS KRY_WDOT_BLOCKS
+static __device__ __align__(256) double kry_static_scratch[KRY_STATIC_PARTIALS + 32];
+#define KRY_STATIC_MAX_DEVICES 64
+static double *g_static_ptr[KRY_STATIC_MAX_DEVICES];   // address of the array on each device, 0 = not asked yet
+
+// Calls on one GPU share that GPU's array: two of them in flight at once race.
+hipError_t kry_launch_wdot_static(int device, const KryGeo &g, const double *x, const double *y, int norm_mode,
+                                  double *result, hipStream_t st)
+{
+	if (device < 0 || device >= KRY_STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
+	double *scratch = __atomic_load_n(&g_static_ptr[device], __ATOMIC_ACQUIRE);
+	if (!scratch) {
+		// once per device, with that device current (the caller made it so)
+		hipError_t e = hipGetSymbolAddress((void **)&scratch, HIP_SYMBOL(kry_static_scratch));
+		if (e != hipSuccess) return e;
+		if (!scratch) return hipErrorInvalidSymbol;
+		__atomic_store_n(&g_static_ptr[device], scratch, __ATOMIC_RELEASE);
+	}
+	const long rows = (long)(g.my + 1) * (g.mz + 1);
+	dim3 grid((unsigned)std::min<long>((rows + NW - 1) / NW, KRY_WDOT_BLOCKS)), block(NT);
+	if (grid.x < 1 || grid.x > KRY_STATIC_PARTIALS) return hipErrorInvalidValue;
+	unsigned *counter = reinterpret_cast<unsigned *>(scratch + KRY_STATIC_PARTIALS);
+	// the ticket must start at zero whatever an earlier (possibly aborted) call left behind
+	hipError_t e = hipMemsetAsync(counter, 0, 256, st);
+	if (e != hipSuccess) return e;
+	KryRed red;
+	red.partial = scratch;
+	red.counter = counter;
+	red.S = nullptr;
+	red.nblk = (int)grid.x;
+	red.phase = PH_NONE;
+	red.out = result;
+	red.out_sqrt = norm_mode ? 1 : 0;
+	hipLaunchKernelGGL(g_wdot, grid, block, 0, st, g, x, y, norm_mode, red);
 	return hipGetLastError();
 }
 

@@ -487,6 +487,8 @@ KryRed make_red(Slab &s, int nblk, int phase)
 	r.S = s.S;
 	r.nblk = nblk;
 	r.phase = phase;
+	r.out = nullptr;
+	r.out_sqrt = 0;
 	return r;
 }
 
@@ -1968,6 +1970,38 @@ int kry_op_l2norm(kry_handle h, const double *v, double *result)
 {
 	if (!h || !v || !result) return KRY_ERR_ARG;
 	return op_dot(h, v, v, 1, result);
+}
+
+int kry_op_dot_static(int device, const double *a, const double *b, const int mx[3], int norm_mode, double *result,
+                      void *stream)
+{
+	if (!a || !b || !mx || !result) { set_err("kry_op_dot_static: null argument"); return KRY_ERR_ARG; }
+	for (int k = 0; k < 3; ++k)
+		if (mx[k] < 1) { set_err("kry_op_dot_static: mx[%d]=%d, need >= 1", k, mx[k]); return KRY_ERR_ARG; }
+	const double n = ((double)mx[0] + 3) * ((double)mx[1] + 3) * ((double)mx[2] + 3);
+	if (n > (double)KRY_STATIC_DOT_MAX_DOUBLES) {
+		set_err("kry_op_dot_static: a field of %d x %d x %d points (%.0f doubles with ghosts) exceeds the limit of %ld doubles",
+		        mx[0] + 1, mx[1] + 1, mx[2] + 1, n, (long)KRY_STATIC_DOT_MAX_DOUBLES);
+		return KRY_ERR_ARG;
+	}
+	int cur = -1;
+	HIPCHK(hipGetDevice(&cur));
+	if (cur != device) HIPCHK(hipSetDevice(device));
+	// the caller's unpadded layout seen through the kernels' index function: row pitch mx+3, grid
+	// index i in column i+1, hence a base pointer one double in front of the field
+	KryGeo g;
+	memset(&g, 0, sizeof g);
+	g.mx = mx[0]; g.my = mx[1]; g.mz = mx[2];
+	g.px = mx[0] + 3;
+	g.ps = (long)g.px * (mx[1] + 3);
+	g.n = g.ps * (mx[2] + 3);
+	hipError_t e = kry_launch_wdot_static(device, g, a - 1, b - 1, norm_mode, result, (hipStream_t)stream);
+	if (cur != device) (void)hipSetDevice(cur);
+	if (e != hipSuccess) {
+		set_err("kry_op_dot_static: %s", hipGetErrorString(e));
+		return KRY_ERR_HIP;
+	}
+	return KRY_OK;
 }
 
 } // extern "C"
