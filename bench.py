@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """Throughput of the BiCGStab(l) stencil solve on MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" is one pass of the outer do{}while loop of the reference's
 solve_int (BICGStab3D/solveLin_BICGStab.C:327-496): 2*l operator
 applications, the vector updates and all dot products.  The workload is the
 512^3 fp64 variable-coefficient stencil (Dxy = 0) with Dirichlet faces; with N
-GPUs the grid is split into N z-slabs (strong scaling: total work fixed).
-Fields are generated on the host, staged to HBM and the solve's prologue is
-run before the timed region; the timed region is K passes on resident data.
+GPUs the grid is split into N z-slabs (strong scaling: total work fixed), one
+process per GPU.  Called with --gpus N > 1 outside torch.distributed.run, the
+script starts the N rank processes itself (before anything in it has touched a
+GPU) and relays rank 0's line.  Fields are generated on the host, staged to HBM
+and the solve's prologue is run before the timed region; the timed region is K
+passes on resident data.
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (HIP events
 recorded on the solver's own stream around every launch of the timed region);
 `cpu_baseline` is the CPU oracle (oracle/, a line-faithful restatement of the
-reference's serial path) timed on one host core on a bounded sample.
+reference's CPU path) timed on the host cores on a bounded sample.  On one GPU
+the line also carries, under `also`, a few passes each of l = 1 on the same grid
+and of the 256^3 constant-coefficient problem (l = 1 and 2).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,6 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 KIND_NAMES = {0: "fused_A0", 1: "fused_A1", 2: "fused_B0", 3: "fused_B0L", 4: "fused_B1L",
               5: "fused_residual", 6: "mgs2", 7: "final"}
+METRIC = "BiCGStab iters/sec + achieved HBM GB/s (fp64 512^3) at 1/2/4/8 MI355X"
 
 
 def kernel_words(L, var, offd):
@@ -50,13 +57,17 @@ def kernel_words(L, var, offd):
             7: 11}                 # phi,r0..r2,u0,u1,u2,rt -> phi,r0,u0
 
 
+def contract_words(L, var):
+    """Doubles per point and pass of the fully fused schedule the metric's byte model is defined on."""
+    return {1: (26 if var else 20), 2: (62 if var else 50)}[L]
+
+
 def measured_traffic(kernel_name, n, L, workload, world):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes
     (profiles/*_hbm_traffic.json), if they were taken on this very workload."""
     import glob
-    if workload == "mixed":
-        return None, None
-    want = "%d^3 fp64 %s-coefficient, l=%d, %d GPU" % (n, "variable" if workload == "var" else "constant", L, world)
+    want = "%d^3 fp64 %s-coefficient, l=%d, %d GPU" % (n, {"var": "variable", "const": "constant",
+                                                            "mixed": "mixed-face variable"}[workload], L, world)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -70,7 +81,6 @@ def measured_traffic(kernel_name, n, L, workload, world):
 def slab_problem(n, nslabs, slab, workload, nz=None):
     """Fields of z-slab `slab` of the n x n x nz problem (nz = n unless given),
     ghost planes included, evaluated from closed forms at global positions."""
-    from krylov_amd import problems as P
     nz = n if nz is None else nz
     mzl = nz // nslabs
     delx = (1.0 / n, 1.0 / n, 1.0 / nz)
@@ -102,6 +112,11 @@ def slab_problem(n, nslabs, slab, workload, nz=None):
         f["Dzz"] = full(1.0 + 0.5 * np.sin(2 * pi * z) * np.cos(2 * pi * x))
         f["rhs"] = full(sinx * siny * sinz)
         f["Dc"] = (1., 1., 1.)
+    elif workload == "poisson":
+        # the 64^3 plumbing case: D = (1,1,1), lambda = 0, rhs = -3 pi^2 sin sin sin
+        f["lam"] = np.zeros(shape)
+        f["rhs"] = full(-3.0 * (pi * pi) * (sinx * siny * sinz))
+        f["Dc"] = (1., 1., 1.)
     else:
         # the reference driver's test 1 (BICGStab3D/main.C:223-229,277,282-284)
         Dc = (1., 1., 10.)
@@ -113,9 +128,13 @@ def slab_problem(n, nslabs, slab, workload, nz=None):
     return f
 
 
-def _cpu_run(n_sample, L, workload, n_full, budget_iters, threads):
-    """One timed oracle solve in a child process (the OpenMP thread count is fixed at start-up)."""
-    import subprocess
+# --------------------------------------------------------------------------- CPU leg
+
+def _cpu_run(n, L, workload, max_outer, eps, threads, split=None):
+    """One timed oracle solve in a child process (thread counts are fixed at start-up).
+    split: None = the serial restatement (or its OpenMP build when threads > 1);
+    (px,py,pz) = the restatement of the reference's `-D parallel` path with one thread per
+    sub-domain of that Cartesian split."""
     code = (
         "import sys, json, time, numpy as np\n"
         "sys.path.insert(0, %r)\n"
@@ -124,46 +143,115 @@ def _cpu_run(n_sample, L, workload, n_full, budget_iters, threads):
         "orc.build()\n"
         "%s\n"
         "f = bench.slab_problem(%d, 1, 0, %r)\n"
-        "var = %r != 'const'\n"
-        "cfg = orc.make_cfg(f['mx'], f['delx'], f['bc'], L=%d, eps=0.0, max_outer=%d, var_coef=var, "
+        "var = %r in ('var', 'mixed')\n"
+        "cfg = orc.make_cfg(f['mx'], f['delx'], f['bc'], L=%d, eps=%r, max_outer=%d, var_coef=var, "
         "use_offdiag=False, Dc=f['Dc'])\n"
         "phi = f['phi'].copy()\n"
         "z = np.zeros_like(phi) if var else None\n"
+        "split = %r\n"
         "t0 = time.perf_counter()\n"
-        "r = orc.solve(cfg, phi, f['rhs'].copy(), f['lam'].copy(), f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
-        "print(json.dumps({'iters': r['iters'], 'seconds': time.perf_counter() - t0}))\n"
-    ) % (ROOT, "orc.use_openmp_build()" if threads > 1 else "", n_sample, workload, workload, L, budget_iters)
+        "if split: r = orc.solve_ranks(cfg, split, phi, f['rhs'].copy(), f['lam'].copy(), f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
+        "else: r = orc.solve(cfg, phi, f['rhs'].copy(), f['lam'].copy(), f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
+        "print(json.dumps({'iters': r['iters'], 'seconds': time.perf_counter() - t0, 'status': r['status'],"
+        " 'final': r['norm_final'] / r['norm_rhs']}))\n"
+    ) % (ROOT, "orc.use_openmp_build()" if (threads > 1 and not split) else "", n, workload, workload, L, eps,
+         max_outer, split)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    d = json.loads(out.stdout.strip().splitlines()[-1])
-    rate = max(d["iters"], 1) / d["seconds"]
-    return rate, rate * ((n_sample + 1) ** 3) / float((n_full + 1) ** 3), max(d["iters"], 1)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr.strip().splitlines()[-1] if out.stderr.strip() else "oracle run failed")
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])   # (the oracle prints the reference's NaN notes)
+    d["iters"] = max(d["iters"], 1)
+    d["rate"] = d["iters"] / d["seconds"]
+    return d
 
 
-def cpu_baseline(n_sample, L, workload, n_full, budget_iters):
-    """The CPU oracle (oracle/krylov_oracle.c, a line-faithful restatement of the
-    reference's serial solver with its un-fused pass structure) on the same
-    workload at n_sample^3 for a few passes, scaled by grid points to n_full^3.
-    Reported: the multi-core figure (the same source with its loops spread over
-    8 threads by OpenMP, standing in for the reference's 2x2x2 MPI ranks) and,
-    in `single_core`, the plain serial build."""
-    cores = min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    r1, v1, it1 = _cpu_run(n_sample, L, workload, n_full, budget_iters, 1)
-    out = {"value": v1, "unit": "iter/s", "cores": 1, "kind": "port",
-           "sample": "%d passes (plus prologue/epilogue residuals) of the same %s-coefficient l=%d solve at %d^3: "
-                     "%.3f iter/s measured on 1 core, scaled by grid points to %d^3"
-                     % (it1, workload, L, n_sample, r1, n_full)}
-    if cores > 1:
+def cpu_baseline(L, workload, n_full, n_sample, iters, cores_wanted):
+    """The CPU oracle next to the GPU line (kind "port": oracle/krylov_oracle.c restates the
+    reference's serial path with its un-fused pass structure, oracle/krylov_oracle_ranks.c its
+    `-D parallel` path with the driver's Cartesian split, one thread per MPI rank):
+      * `value`: the headline workload at n_sample^3 for `iters` passes on P = 8 ranks
+        (2 x 2 x 2, BICGStab3D/main.C:146-150), scaled by grid points to n_full^3;
+      * `single_core`: the serial restatement, same sample, fewer passes;
+      * `c1`: the 64^3 plumbing case solved to 1e-6 in full on one core: the reference driver's
+        test 1 (constant coefficients, l = 2) and the pure Poisson problem with l = 1 (its
+        right-hand side is an eigenvector of the operator: one pass; with l = 2 the reference
+        breaks down on it with "alpha is nan")."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    scale = ((n_sample + 1) ** 3) / float((n_full + 1) ** 3)
+    desc = "%s-coefficient l=%d" % ("variable" if workload != "const" else "constant", L)
+    out = {"unit": "iter/s", "kind": "port"}
+    one = _cpu_run(n_sample, L, workload, max(3, iters // 3), 0.0, 1)
+    out["single_core"] = {"value": one["rate"] * scale, "cores": 1, "measured_at_sample": one["rate"],
+                          "sample": "%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3, serial "
+                                    "restatement on 1 core; scaled by grid points to %d^3"
+                                    % (one["iters"], desc, n_sample, n_full)}
+    out.update(value=out["single_core"]["value"], cores=1, sample=out["single_core"]["sample"])
+    if avail >= 8 and cores_wanted >= 8:
         try:
-            rc, vc, itc = _cpu_run(n_sample, L, workload, n_full, 2 * budget_iters, cores)
-            out = {"value": vc, "unit": "iter/s", "cores": cores, "kind": "port",
-                   "sample": "%d passes (plus prologue/epilogue residuals) of the same %s-coefficient l=%d solve at "
-                             "%d^3: %.3f iter/s measured on %d cores (OpenMP build of the oracle), scaled by grid "
-                             "points to %d^3" % (itc, workload, L, n_sample, rc, cores, n_full),
-                   "single_core": {"value": v1, "measured_at_sample": r1}}
-        except Exception as e:          # keep the single-core figure
-            out["sample"] += " (multi-core run failed: %s)" % e
+            many = _cpu_run(n_sample, L, workload, iters, 0.0, 8, split=(2, 2, 2))
+            out.update(value=many["rate"] * scale, cores=8, measured_at_sample=many["rate"],
+                       sample="%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3 on 8 host cores: "
+                              "restatement of the reference's MPI path, 2x2x2 sub-domains, one thread per rank, "
+                              "%.3f iter/s measured; scaled by grid points to %d^3"
+                              % (many["iters"], desc, n_sample, many["rate"], n_full))
+        except Exception as e:
+            out["sample"] += " (8-rank run failed: %s)" % e
+    out["c1"] = []
+    for wl, cl, name in (("const", 2, "reference driver test 1 (D = 1,1,10; lambda = 0.2 x y^2 z)"),
+                         ("poisson", 1, "Poisson (D = 1,1,1; lambda = 0)")):
+        try:
+            c1 = _cpu_run(64, cl, wl, 0, 1e-6, 1)
+            out["c1"].append({"workload": "64^3 %s, Dirichlet, l=%d, eps 1e-6, serial restatement, 1 core, full solve"
+                                          % (name, cl), "iterations": c1["iters"], "status": c1["status"],
+                              "seconds": round(c1["seconds"], 3), "iter_per_s": round(c1["rate"], 2),
+                              "relative_residual": c1["final"]})
+        except Exception as e:
+            out["c1"].append({"workload": name, "error": str(e)})
     return out
+
+
+# ------------------------------------------------------------------------- launcher
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(argv, n, timeout=None):
+    """Start n rank processes of this script (fresh interpreters: nothing here has touched a
+    GPU), rank 0's stdout is relayed, everything else goes to stderr.  Returns the exit code."""
+    port = free_port()
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                KRY_BENCH_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    deadline = time.time() + (timeout or float(os.environ.get("KRY_BENCH_TIMEOUT", "1500")))
+    line, rc = b"", 0
+    try:
+        line = procs[0].communicate(timeout=max(1.0, deadline - time.time()))[0]
+        for q in procs[1:]:
+            q.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    for q in procs:
+        if q.returncode not in (0, None):
+            rc = rc or q.returncode
+    sys.stdout.write(line.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
 
 
 def claim_stdout():
@@ -174,6 +262,50 @@ def claim_stdout():
     real = os.dup(1)
     os.dup2(2, 1)
     return real
+
+
+# ---------------------------------------------------------------------- measurement
+
+def kernel_table(s0, s1, L, var, npts_local):
+    """Per-kernel average launch time and algorithmic rate between two kry_stats snapshots."""
+    kern = {}
+    for k, w in kernel_words(L, var, False).items():
+        calls = s1.kernel_calls[k] - s0.kernel_calls[k]
+        ms = s1.kernel_ms[k] - s0.kernel_ms[k]
+        if calls > 0:
+            kern[k] = dict(name=KIND_NAMES[k], calls=calls, avg_ms=ms / calls, words=w,
+                           gbs=8.0 * w * npts_local / (ms / calls * 1e-3) / 1e9)
+    return kern
+
+
+def single_gpu_passes(capi, device, n, L, workload, steps, warmup, fields=None):
+    """A few passes of another configuration on this GPU (resident fields, prologue outside
+    the timed region), for the `also` entries of the line."""
+    f = fields or slab_problem(n, 1, 0, workload)
+    var = workload != "const"
+    with capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, devices=(device,)) as s:
+        if var:
+            s.load_var(f["phi"], f["rhs"], f["lam"], f["Dxx"], f["Dyy"], f["Dzz"], None, False)
+        else:
+            s.load_const(f["phi"], f["rhs"], f["lam"], f["Dc"])
+        s.iterate(warmup)
+        a = s.stats()
+        t0 = time.perf_counter()
+        st = s.iterate(steps)
+        dt = time.perf_counter() - t0
+        b = s.stats()
+        hist = s.history()
+    npts = float(n + 1) ** 3
+    kern = kernel_table(a, b, L, var, npts)
+    moved = sum(kernel_words(L, var, False).values())
+    ms = dt / steps * 1e3
+    return {"workload": "%d^3 fp64 %s-coefficient, l=%d, Dirichlet faces" % (n, "variable" if var else "constant", L),
+            "value": round(steps / dt, 2), "unit": "iter/s", "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
+            "valid": bool(st == 0 and b.iterations == warmup + steps and np.all(np.isfinite(hist))),
+            "frac_of_hbm_peak_contract_words": round(8.0 * contract_words(L, var) * npts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_of_hbm_peak_moved_words": round(8.0 * moved * npts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels": {v["name"]: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["gbs"], 1), "words": v["words"]}
+                        for v in kern.values()}}
 
 
 def main():
@@ -189,19 +321,36 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: a GRID x GRID x 128 block per GPU (GRID = 1024 gives the 1024^3 problem on 8 GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=192)
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the ranks rendezvous, and rank 0 prints who took part (launcher check)")
+    ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=256)
+    ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
-    real_stdout = claim_stdout()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # called directly: become the launcher.  Nothing above loads the solver library or torch.
+        return launch_ranks(sys.argv[1:], args.gpus)
+
+    real_stdout = claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    if args.dry_run:
+        who = [(rank, local_rank, os.getpid())]
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+            got = [None] * world
+            dist.all_gather_object(got, who[0])
+            who = got
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"dry_run": True, "n_gpus": world, "ranks": who, "launched_by": "bench.py"
+                                               if os.environ.get("KRY_BENCH_LAUNCHED") else "other"}) + "\n").encode())
+        return 0
     # per-kernel HIP events only where the roofline is reported (one GPU)
     os.environ.setdefault("KRY_PROFILE", "1" if world == 1 else "0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -211,10 +360,16 @@ def main():
     # torch.distributed afterwards and for the control plane only
     from krylov_amd import capi
     capi.lib()
-    capi.device_check(int(os.environ.get("KRY_BENCH_DEVICE", local_rank)))
+    ndev = capi.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device")
+    # one GPU per rank; with fewer GPUs than ranks (a rehearsal on a smaller box) ranks share them
+    device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank % ndev))
+    capi.device_check(device)
 
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
 
@@ -224,30 +379,38 @@ def main():
         sys.exit("grid size %d is not divisible by %d slabs" % (nz, world))
     f = slab_problem(n, world, rank, args.workload, nz)
 
-    device = int(os.environ.get("KRY_BENCH_DEVICE", local_rank))
-    solver = capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, nslabs=world,
-                         slab_begin=rank, slab_count=1, devices=(device,))
-    transport = "none"
+    def new_solver():
+        return capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, nslabs=world,
+                           slab_begin=rank, slab_count=1, devices=(device,))
+
+    def all_ok(mine):
+        flag = torch.tensor([1 if mine else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag[0]) == 1
+
+    solver = new_solver()
+    transport, rccl = "none", {"ranks": 0, "error": None}
     if world > 1:
-        import torch
         transport = "rccl"
+        err = None
         try:
             uid = [capi.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             solver.comm_init(uid[0], rank, world)
-            ok_local = 1
         except Exception as e:           # no usable RCCL: keep the run alive on a host-staged path
+            err = str(e)
             sys.stderr.write("rank %d: RCCL communicator unavailable (%s)\n" % (rank, e))
-            ok_local = 0
-        flag = torch.tensor([ok_local])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if any(errs):
             from krylov_amd import gloo_transport
-            transport = "gloo-staged (RCCL unavailable)"
+            rccl["error"] = next(e for e in errs if e)
+            transport = "gloo-staged (RCCL refused)"
             solver.close()
-            solver = capi.Solver(f["mx"], f["delx"], f["bc"], L=L, eps=0.0, max_outer=0, nslabs=world,
-                                 slab_begin=rank, slab_count=1, devices=(device,))
+            solver = new_solver()
             solver.comm_init_callbacks(rank, world, *gloo_transport.make(rank, world))
+        else:
+            rccl["ranks"] = int(solver.stats().rccl_ranks)
 
     def barrier():
         if dist is not None:
@@ -259,11 +422,6 @@ def main():
         else:
             solver.load_const(f["phi"], f["rhs"], f["lam"], f["Dc"])
 
-    def all_ok(mine):
-        flag = torch.tensor([1 if mine else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return int(flag[0]) == 1
-
     # Exchange between the ranks: through the transport (per dot product one RCCL all-reduce and
     # two small kernels, per operator output one grouped send/receive), with the dot products
     # all-reduced by the reduction kernels themselves through device mailboxes ("mailbox"), or
@@ -271,9 +429,9 @@ def main():
     # All are tried on a few passes of this very problem; the fastest one that reproduces the
     # transport's residuals is used for the measurement.  KRY_BENCH_REDUCE=transport skips the
     # trial, =mailbox / ="mapped memory" prefers that route when it is valid.
-    reduction, trial = "none", None
+    exchange, trial, why = "none", None, "one GPU: nothing to exchange"
     if world > 1:
-        reduction = "transport"
+        exchange, why = "transport", "KRY_BENCH_REDUCE=transport"
         want = os.environ.get("KRY_BENCH_REDUCE", "auto")
         if want != "transport":
             os.environ.setdefault("KRY_MAIL_TIMEOUT_MS", "5000")
@@ -284,16 +442,22 @@ def main():
                 mine = None
             handles = [None] * world
             dist.all_gather_object(handles, mine)
-            connected = False
+            connected, cerr = False, None
             if all(h is not None for h in handles):
                 try:
                     solver.mail_connect(rank, world, handles)
                     connected = True
                 except Exception as e:
+                    cerr = str(e)
                     sys.stderr.write("rank %d: mailboxes not connected (%s)\n" % (rank, e))
+            else:
+                cerr = "a rank could not export its mailbox"
             if not all_ok(connected):
                 if connected:
                     solver.mail_enable(0)
+                cerrs = [None] * world
+                dist.all_gather_object(cerrs, cerr)
+                why = "the ranks' GPUs cannot map each other's memory (%s)" % next((e for e in cerrs if e), "?")
             else:
                 trial, hists = {}, {}
                 modes = {"mailbox": capi.KRY_MAIL_SUMS, "mapped memory": capi.KRY_MAIL_SUMS | capi.KRY_MAIL_PLANES,
@@ -325,7 +489,10 @@ def main():
                     if all_ok(same) and (trial[name] < trial[best] or want == name):
                         best = name
                 solver.mail_enable(modes[best])
-                reduction = best
+                exchange = best
+                why = ("fastest of the routes tried on 6 passes of this problem that reproduces the transport's residuals"
+                       if want == "auto" else "KRY_BENCH_REDUCE=%s" % want)
+                trial = {k: (round(v, 4) if np.isfinite(v) else None) for k, v in trial.items()}
         barrier()
 
     t_stage = time.perf_counter()
@@ -334,8 +501,6 @@ def main():
 
     st = solver.iterate(args.warmup) if args.warmup > 0 else 0
     s0 = solver.stats()
-    k_ms0 = list(s0.kernel_ms)
-    k_n0 = list(s0.kernel_calls)
 
     barrier()
     t0 = time.perf_counter()
@@ -344,7 +509,6 @@ def main():
     barrier()
     elapsed = t1 - t0
     if dist is not None:
-        import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
@@ -354,29 +518,27 @@ def main():
     ok = (st == 0 and s1.iterations == args.warmup + args.steps and np.all(np.isfinite(hist)))
 
     # Several GPUs: the timed region runs without per-kernel events (rank 0 would lag behind the
-    # others by their cost); the kernel table and the roofline come from a few extra passes.
-    probe = 0
+    # others by their cost); the kernel table, the roofline and the transport's share of a pass
+    # come from a few extra passes with the events on.
+    probe, probe_ms = 0, None
+    sa, sb = s0, s1
     if world > 1 and all_ok(ok):          # (a collective decision: every rank runs the extra passes or none)
         try:
             solver.set_profile(True)
-            k_ms0, k_n0 = list(s1.kernel_ms), list(s1.kernel_calls)
+            sa = solver.stats()
             probe = 6
+            barrier()
+            tp = time.perf_counter()
             solver.iterate(probe)
-            s1 = solver.stats()
+            probe_ms = (time.perf_counter() - tp) / probe * 1e3
+            sb = solver.stats()
         except Exception as e:
             sys.stderr.write("rank %d: no per-kernel times (%s)\n" % (rank, e))
             probe = 0
 
     if rank == 0:
         npts = float(n + 1) ** 2 * (nz + 1)
-        words = kernel_words(L, var, False)
-        kern = {}
-        for k, w in words.items():
-            calls = s1.kernel_calls[k] - k_n0[k]
-            ms = s1.kernel_ms[k] - k_ms0[k]
-            if calls > 0:
-                kern[k] = dict(name=KIND_NAMES[k], calls=calls, avg_ms=ms / calls, words=w,
-                               gbs=8.0 * w * npts / world / (ms / calls * 1e-3) / 1e9)
+        kern = kernel_table(sa, sb, L, var, npts / world)
         dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["calls"]) if kern else None
         roof = None
         if dom is not None:
@@ -385,16 +547,35 @@ def main():
                     "traffic": None, "avg_launch_ms": round(kern[dom]["avg_ms"], 4),
                     "algorithmic_bytes_per_launch": 8.0 * kern[dom]["words"] * npts / world}
             if probe:
-                roof["measured_on"] = "%d passes after the timed region, rank 0; launches include waits for ghost planes" % probe
+                roof["measured_on"] = "%d passes after the timed region, rank 0" % probe
             tr, src = measured_traffic(kern[dom]["name"], n, L, args.workload, world)
             if tr is not None:
                 roof["traffic"] = tr
                 roof["traffic_source"] = "profiles/" + src
         ms_step = elapsed / args.steps * 1e3
-        W = {1: (26 if var else 20), 2: (62 if var else 50)}[L]
+        W = contract_words(L, var)
+        moved = sum(kernel_words(L, var, False).values())
         whole = 8.0 * W * npts / (ms_step * 1e-3) / 1e9
+        whole_moved = 8.0 * moved * npts / (ms_step * 1e-3) / 1e9
+        # share of a pass spent exchanging (rank 0): mapped-memory routes over the timed region
+        # (the kernels count their own waiting), the transport over the probe passes (HIP events)
+        wait = None
+        if world > 1:
+            if probe and (sb.comm_wait_calls[0] or sb.comm_wait_calls[1]) and exchange != "mapped memory":
+                base, per = sa, probe * probe_ms
+                ar = (sb.comm_wait_ms[0] - base.comm_wait_ms[0]) / per
+                hl = (sb.comm_wait_ms[1] - base.comm_wait_ms[1]) / per
+                basis = "HIP events around the transport's calls and the main stream's waits, %d probe passes" % probe
+                if exchange == "mailbox":
+                    basis = "all-reduce: time counted by the reducing kernels; ghost planes: " + basis
+            else:
+                per = args.steps * ms_step
+                ar = (s1.comm_wait_ms[0] - s0.comm_wait_ms[0]) / per
+                hl = (s1.comm_wait_ms[1] - s0.comm_wait_ms[1]) / per
+                basis = "time counted by the waiting kernels themselves over the timed region"
+            wait = {"allreduce": round(ar, 4), "halo": round(hl, 4), "basis": basis}
         out = {
-            "metric": "BiCGStab iters/sec + achieved HBM GB/s (fp64 512^3) at 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": round(args.steps / elapsed, 3), "unit": "iter/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64",
@@ -405,23 +586,43 @@ def main():
                                                      "mixed Dirichlet/extrapolating" if args.workload == "mixed"
                                                      else "Dirichlet", world),
                        "grid": n, "l": L, "coefficients": args.workload, "parallelism": "z-slabs x%d" % world,
-                       "transport": transport, "exchange": reduction,
-                       "exchange_trial_ms_per_pass": trial},
+                       "launched_by": "bench.py" if os.environ.get("KRY_BENCH_LAUNCHED") else
+                                      ("torch.distributed.run" if world > 1 else "direct"),
+                       "devices_visible": ndev, "ranks_per_device": -(-world // ndev),
+                       "transport": transport, "rccl_ranks": rccl["ranks"], "rccl_error": rccl["error"],
+                       "exchange": exchange, "exchange_reason": why,
+                       "exchange_trial_ms_per_pass": trial, "wait_share_of_pass": wait},
             "valid": bool(ok), "solver_path": s1.fused,
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),
             "iteration_words_per_point": W,
+            "iteration_words_moved": moved,
+            "iteration_GBps_moved": round(whole_moved, 1),
+            "iteration_frac_of_hbm_peak_moved": round(whole_moved / HBM_PEAK_GBS / world, 4),
             "stage_s": round(t_stage, 3),
             "residual_after": float(hist[-1]) if len(hist) else None,
             "kernels": {v["name"]: {"avg_ms": round(v["avg_ms"], 4), "GBps": round(v["gbs"], 1),
                                     "words": v["words"], "calls": v["calls"]} for v in kern.values()},
             "roofline": roof,
         }
+    solver.close()
+
+    if rank == 0:
+        if world == 1 and not args.weak and not args.no_also:
+            # the same driver run also times l = 1 on this grid and the 256^3 constant-coefficient problem
+            also = []
+            for (an, aL, awl, asteps, awarm) in ((n, 1 if L == 2 else 2, args.workload, 20, 3), (256, 1, "const", 200, 20),
+                                                 (256, 2, "const", 100, 10)):
+                try:
+                    also.append(single_gpu_passes(capi, device, an, aL, awl, asteps, awarm,
+                                                  fields=f if (an == n and awl == args.workload) else None))
+                except Exception as e:
+                    also.append({"workload": "%d^3 %s l=%d" % (an, awl, aL), "error": str(e)})
+            out["also"] = also
         if world == 1 and not args.no_cpu and not args.weak:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, L, args.workload, n, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(L, args.workload, n, args.cpu_n, args.cpu_iters, 8)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
-    solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -94,6 +94,13 @@ typedef struct kry_stats {
 	int    chunk_planes;     /*   rows per fused tile, planes per fused chunk,               */
 	int    stream_blocks;    /*   grid target of the streaming kernels                        */
 	double enqueue_ms;       /* host time spent queueing kernels and transfers of the passes  */
+	/* Exchange between the sub-domains of a split, device time on this process's first slab since
+	 * the last load: [0] the all-reduces of the dot products, [1] waiting for ghost planes.
+	 * Through the transport they are timed by HIP events while per-kernel timing is on
+	 * (kry_set_profile); through mapped device memory the kernels count their own waiting time. */
+	double comm_wait_ms[2];
+	int    comm_wait_calls[2];   /* timed transport calls (0 on the mapped-memory routes) */
+	int    rccl_ranks;       /* ranks of the RCCL communicator (ncclCommCount), 0: none in use */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;

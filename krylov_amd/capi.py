@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkrylov_amd.so")
+# KRY_LIB_PATH: another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("KRY_LIB_PATH") or os.path.join(_HERE, "libkrylov_amd.so")
 
 KRY_MAX_SLABS = 16
 KRY_UID_BYTES = 128
@@ -66,6 +67,9 @@ class KryStats(C.Structure):
         ("chunk_planes", C.c_int),
         ("stream_blocks", C.c_int),
         ("enqueue_ms", C.c_double),
+        ("comm_wait_ms", C.c_double * 2),
+        ("comm_wait_calls", C.c_int * 2),
+        ("rccl_ranks", C.c_int),
     ]
 
 
@@ -170,6 +174,15 @@ def _ptr(a):
 def device_check(device=0):
     """Raises KryError unless HIP device `device` accepts work from this library."""
     return _check(lib().kry_device_check(int(device)), "kry_device_check")
+
+
+def device_count():
+    """HIP devices visible to the solver library's runtime."""
+    n = C.c_int(0)
+    L = lib()
+    L.hipGetDeviceCount.argtypes = [C.POINTER(C.c_int)]
+    L.hipGetDeviceCount.restype = C.c_int
+    return n.value if L.hipGetDeviceCount(C.byref(n)) == 0 else 0
 
 
 def comm_selftest(device=0):

@@ -16,6 +16,7 @@ struct Api {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +53,7 @@ bool load_api()
 	          sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") && sym(g_api.GroupStart, "ncclGroupStart") &&
 	          sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.GetErrorString, "ncclGetErrorString");
 	if (!ok) { g_cerr = "librccl lacks a required symbol"; dlclose(g_api.lib); g_api.lib = nullptr; }
+	else sym(g_api.CommCount, "ncclCommCount");
 	return ok;
 }
 
@@ -94,6 +96,14 @@ int KryComm::init(const void *uid, int rank, int nranks)
 	rank_ = rank;
 	nranks_ = nranks;
 	return 0;
+}
+
+int KryComm::rccl_ranks() const
+{
+	int n = 0;
+	if (!comm_ || !g_api.CommCount) return 0;
+	if (g_api.CommCount(static_cast<ncclComm_t>(comm_), &n) != ncclSuccess) return 0;
+	return n;
 }
 
 int KryComm::init_callbacks(int rank, int nranks, allreduce_fn ar, halo_fn hl, void *ctx)

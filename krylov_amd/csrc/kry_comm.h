@@ -27,6 +27,8 @@ public:
 	void destroy();
 	bool active() const { return comm_ != nullptr || cb_allreduce_ != nullptr || link_self_ != nullptr; }
 	bool has_transport() const { return comm_ != nullptr || cb_allreduce_ != nullptr; }
+	// ranks the RCCL communicator reports (ncclCommCount); 0 without one
+	int rccl_ranks() const;
 	int rank() const { return rank_; }
 	int nranks() const { return nranks_; }
 

@@ -85,6 +85,8 @@ struct KryState {
 	int local_scalars;           // 1: the reducing kernel also advances the recurrences
 	int pad_[2];
 	const KryMail *mail;         // not null: sums are all-reduced over the ranks' mailboxes by the reducing kernel
+	long long wait_sum_ticks;    // wall_clock64 ticks the reducing kernels spent in the mailbox all-reduce since the load
+	long long wait_halo_ticks;   // ... and the ghost-plane kernels waiting for the neighbours' planes
 	double hist[KRY_HIST_CAP];
 };
 

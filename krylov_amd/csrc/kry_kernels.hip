@@ -178,6 +178,7 @@ __device__ inline void mail_allreduce(double (*red)[ND], const KryRed &r)
 	}
 	if (tid == 0) failed = 0;
 	__syncthreads();
+	const long long t_begin = wall_clock64();
 	const unsigned long long seq = *seqp + 1ull;
 	const long slot0 = KRY_MAIL_SLOT + (long)(seq & 1ull) * n * KRY_MAIL_SLOT;
 	for (int p = tid; p < n; p += NT) {
@@ -209,6 +210,7 @@ __device__ inline void mail_allreduce(double (*red)[ND], const KryRed &r)
 			r.S->sums[k] = failed ? __builtin_nan("") : v;
 		}
 		*seqp = seq;
+		r.S->wait_sum_ticks += wall_clock64() - t_begin;
 		__hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (failed) {
 			r.S->status = -3;    // KRY_ERR_COMM
@@ -403,8 +405,11 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // i = mx is overwritten by either face type before anything reads it,
 // BoundaryHandler.C:444-460); its boundary treatment and the boundary-plane terms
 // of the dot products follow in g_bc and k_surf.
+#ifndef KRY_FUSED_MINW
+#define KRY_FUSED_MINW 1     // waves per SIMD the 8-row field-coefficient tiles are compiled for
+#endif
 template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN>
-__global__ __launch_bounds__(NT) void k_fused(const KryFused a)
+__global__ __launch_bounds__(NT, (TY == 8 && VAR && !OFFD) ? KRY_FUSED_MINW : 1) void k_fused(const KryFused a)
 {
 	constexpr int VD = TY / NW;                 // rows per thread
 	constexpr int ND = KindTraits<KIND>::ND;
@@ -1076,6 +1081,7 @@ __global__ __launch_bounds__(NT) void k_halo_pull(KryHaloSide lo, KryHaloSide hi
 			}
 		}
 		failed = bad;
+		if (blockIdx.x == 0) S->wait_halo_ticks += wall_clock64() - t0;
 	}
 	__syncthreads();
 	if (failed) {

@@ -142,8 +142,9 @@ struct kry_solver {
 	bool profile = false;
 	bool overlap = true;       // halo exchange concurrent with the interior chunks
 	Prof prof;
-	double kernel_ms[8] = {0};
-	int kernel_calls[8] = {0};
+	double kernel_ms[10] = {0};   // 0..7: kernel kinds; 8: all-reduces of the transport, 9: waits for ghost planes
+	int kernel_calls[10] = {0};
+	double tick_ms = 1e-5;        // milliseconds per wall_clock64 tick of the first slab's device
 	int debug = 0;
 	// generic path scalars
 	double g_rho0 = 1, g_alpha = 0, g_omega = 1;
@@ -305,7 +306,11 @@ int reduce_sums(kry_solver *h, int phase)
 		for (int i = 1; i < ns; ++i) HIPCHK(hipStreamWaitEvent(s0.st, h->slabs[i].ev, 0));
 		HIPCHK(kry_launch_sum_slabs(s0.gather, ns, tot, s0.st));
 	}
-	if (remote) CHK(h->comm.allreduce_sum(tot, KRY_NSUMS, s0.st));
+	if (remote) {
+		prof_begin(h, s0, 8);
+		CHK(h->comm.allreduce_sum(tot, KRY_NSUMS, s0.st));
+		prof_end(h, s0);
+	}
 	if (ns > 1) {
 		HIPCHK(hipEventRecord(s0.ev_in, s0.st));
 		for (int i = 0; i < ns; ++i) {
@@ -412,9 +417,11 @@ int exchange_halo(kry_solver *h, std::vector<double *> &f)
 		const KryGeo &g = s.g;
 		double *b = f[0];
 		HIPCHK(hipSetDevice(s.device));
+		prof_begin(h, s, 9);
 		CHK(h->comm.halo(g.has_lo ? h->rank_of(h->co[0], h->co[1], h->co[2] - 1) : -1, b + 2L * g.ps, b,
 		                 g.has_hi ? h->rank_of(h->co[0], h->co[1], h->co[2] + 1) : -1, b + (long)g.mz * g.ps,
 		                 b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st));
+		prof_end(h, s);
 	}
 	return 0;
 }
@@ -465,9 +472,12 @@ int exchange_halo_end(kry_solver *h)
 	for (int i = 0; i < ns; ++i) {
 		Slab &s = h->slabs[i];
 		HIPCHK(hipSetDevice(s.device));
+		// (timed: how long the main stream sits idle until the planes are there)
+		if (h->comm.active()) prof_begin(h, s, 9);
 		HIPCHK(hipStreamWaitEvent(s.st, s.ev_halo, 0));
 		if (i > 0) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i - 1].ev_halo, 0));
 		if (i + 1 < ns) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i + 1].ev_halo, 0));
+		if (h->comm.active()) prof_end(h, s);
 	}
 	return 0;
 }
@@ -1322,6 +1332,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 		}
 	}
 	h->loaded = true;
+	for (int k = 8; k < 10; ++k) { h->kernel_ms[k] = 0; h->kernel_calls[k] = 0; }
 	h->solve_ms = 0;
 	h->enqueue_ms = 0;
 	CHK(prologue(h));
@@ -1505,6 +1516,11 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		return 0;
 	};
 	st = build();
+	if (st >= 0) {
+		int khz = 0;
+		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->slabs[0].device) == hipSuccess && khz > 0)
+			h->tick_ms = 1. / khz;
+	}
 	if (st >= 0 && !h->zc_fixed) {
 		// planes per fused chunk: long chunks re-read fewer halo planes, but the grid
 		// should still hold about a thousand blocks
@@ -1824,6 +1840,13 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	                    ((double)h->mzl * h->d.nslabs + 1);
 	o->bytes_per_iter = 8.0 * W * npts;
 	for (int k = 0; k < 8; ++k) { o->kernel_ms[k] = h->kernel_ms[k]; o->kernel_calls[k] = h->kernel_calls[k]; }
+	for (int k = 0; k < 2; ++k) { o->comm_wait_ms[k] = h->kernel_ms[8 + k]; o->comm_wait_calls[k] = h->kernel_calls[8 + k]; }
+	if (h->loaded && h->fused && !h->slabs.empty() && h->slabs[0].Sh) {
+		// the mapped-memory routes: waiting time counted by the kernels (head of KryState, fetched by poll_state)
+		o->comm_wait_ms[0] += h->slabs[0].Sh->wait_sum_ticks * h->tick_ms;
+		o->comm_wait_ms[1] += h->slabs[0].Sh->wait_halo_ticks * h->tick_ms;
+	}
+	o->rccl_ranks = h->comm.rccl_ranks();
 	o->tile_rows = h->gen ? 8 : h->ty;
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;

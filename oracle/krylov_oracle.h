@@ -59,6 +59,16 @@ int orc_solve(const orc_cfg *cfg, double *phi, double *rhs, double *lambda,
               double *Dxx, double *Dyy, double *Dzz, double *Dxy,
               double *hist, int hist_cap, orc_out *out);
 
+/* krylov_oracle_ranks.c: the same solve as the reference's `-D parallel` build runs it, on
+ * np[0]*np[1]*np[2] sub-domains (one thread per MPI rank; BICGStab3D/mpi_manager.C:56-408,
+ * BICGStab3D/BoundaryHandler.C:579-1045).  Fields are the GLOBAL arrays, phi returns the
+ * assembled solution; every mx[d] must be a multiple of np[d].  Returns out->status, -1 for a
+ * split that does not divide the grid.  No reduction hook: sums run in the reference's order
+ * per rank and in rank order across ranks. */
+int orc_solve_ranks(const orc_cfg *cfg, const int np[3], double *phi, const double *rhs,
+                    const double *lambda, const double *Dxx, const double *Dyy, const double *Dzz,
+                    const double *Dxy, double *hist, int hist_cap, orc_out *out);
+
 /* Reduction call sites of orc_solve, for orc_set_reduce_hook. */
 enum {
 	ORC_SITE_NORM_RHS = 0,  /* l2(rhs)                     solveLin_BICGStab.C:268 */

@@ -41,7 +41,7 @@ class OrcOut(C.Structure):
 
 def build(force=False):
     """Compile the oracle with the committed Makefile (gcc only)."""
-    srcs = [os.path.join(_HERE, f) for f in ("krylov_oracle.c", "gpu_order.c", "krylov_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("krylov_oracle.c", "gpu_order.c", "krylov_oracle_ranks.c", "krylov_oracle.h")]
     if (not force and os.path.exists(_LIB)
             and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
         return _LIB
@@ -75,6 +75,9 @@ def lib():
         L.orc_solve.restype = C.c_int
         L.orc_solve.argtypes = [P(OrcCfg), _dp, _dp, _dp, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, _dp, C.c_int, P(OrcOut)]
+        L.orc_solve_ranks.restype = C.c_int
+        L.orc_solve_ranks.argtypes = [P(OrcCfg), C.c_int * 3, _dp, _dp, _dp, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, _dp, C.c_int, P(OrcOut)]
         L.orc_do_bcs.restype = None
         L.orc_do_bcs.argtypes = [P(OrcCfg), _dp]
         L.orc_spmv_const.restype = None
@@ -126,6 +129,20 @@ def solve(cfg, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4
     out = OrcOut()
     st = lib().orc_solve(C.byref(cfg), phi, rhs, lam, _ptr(Dxx), _ptr(Dyy), _ptr(Dzz),
                          _ptr(Dxy), hist, hist_cap, C.byref(out))
+    n = min(out.iters, hist_cap)
+    return dict(status=st, iters=out.iters, norm_rhs=out.norm_rhs, norm_init=out.norm_init,
+                norm_final=out.norm_final, norm_true=out.norm_true, history=hist[:n].copy())
+
+
+def solve_ranks(cfg, nproc, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4096):
+    """The solve as the reference's MPI build runs it on nproc = (px, py, pz) sub-domains, one
+    thread per rank (krylov_oracle_ranks.c).  Arrays are the GLOBAL boxes; phi is updated in place."""
+    hist = np.zeros(max(hist_cap, 1), dtype=np.float64)
+    out = OrcOut()
+    st = lib().orc_solve_ranks(C.byref(cfg), (C.c_int * 3)(*nproc), phi, rhs, lam, _ptr(Dxx), _ptr(Dyy), _ptr(Dzz),
+                               _ptr(Dxy), hist, hist_cap, C.byref(out))
+    if st < 0:
+        raise ValueError("the split %s does not divide the grid" % (tuple(nproc),))
     n = min(out.iters, hist_cap)
     return dict(status=st, iters=out.iters, norm_rhs=out.norm_rhs, norm_init=out.norm_init,
                 norm_final=out.norm_final, norm_true=out.norm_true, history=hist[:n].copy())

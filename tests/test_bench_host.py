@@ -20,6 +20,42 @@ def test_slab_fields_tile_the_global_fields(workload, nslabs):
             assert np.array_equal(part[key], whole[key][s * mzl: s * mzl + mzl + 3]), key
 
 
+def test_direct_call_with_several_gpus_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside torch.distributed.run starts N fresh rank processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) and relays rank 0's
+    one line; --dry-run keeps the ranks off the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, bench.__file__, "--gpus", "3", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["launched_by"] == "bench.py"
+    assert sorted(r[0] for r in d["ranks"]) == [0, 1, 2] and len({r[2] for r in d["ranks"]}) == 3
+
+
+def test_launcher_reports_a_failing_rank():
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["KRY_LIB_PATH"] = "/nonexistent/libkrylov_amd.so"      # the ranks cannot load the solver library
+    out = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+
+
+def test_contract_and_moved_words():
+    for L in (1, 2):
+        for var in (False, True):
+            assert sum(bench.kernel_words(L, var, False).values()) <= bench.contract_words(L, var)
+
+
 def test_kernel_byte_model_totals():
     # doubles per point and pass under the fully fused schedule: 20/26 (l=1), 50/62 (l=2)
     assert sum(bench.kernel_words(1, False, False).values()) == 19      # contract: 20
