@@ -51,7 +51,9 @@ def compare(orc, p, L, eps=1e-6, max_outer=0, flags=0, expect_fused=None, first_
         assert got["history"][-1] <= eps * want["norm_rhs"]
         assert abs(got["iters"] - want["iters"]) <= max(8, want["iters"] // 3)
         assert true_residual(orc, p, got["phi"]) <= 2.0 * eps * want["norm_rhs"]
-        assert rel_l2(points(got["phi"]), points(want["phi"])) <= 1e-3
+        # both solutions carry an error of the order of the tolerance they were solved to (the tight
+        # form of this check, 1e-9 at eps = 1e-12, is tests/test_gpu_parity_pin.py)
+        assert rel_l2(points(got["phi"]), points(want["phi"])) <= 50 * eps
     else:
         assert got["iters"] == want["iters"]
     return want, got
