@@ -5,7 +5,9 @@
 
 #define KRY_TXW 128   // fused tile width in grid points
 #define KRY_WDOT_BLOCKS 4096   // largest grid of the generic weighted dot
+#ifndef KRY_SEG
 #define KRY_SEG 2048  // doubles of a plane handled per block and plane by the streaming kernels
+#endif
 #define KRY_SURF_BLOCKS 512    // largest grid of the boundary-plane dot kernel
 
 // fused stencil kernel kinds

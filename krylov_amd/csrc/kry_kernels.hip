@@ -22,7 +22,7 @@
 #define NW (NT / 64)           // wavefronts per block
 #define TXW KRY_TXW            // tile width in grid points = one 1 KiB wave load of double2
 #define QOFF 2                  // streaming kernels start a plane at column 2: 128-byte aligned wave loads
-#define SEG2 1024               // double2 elements of a plane segment handled per block and plane
+#define SEG2 (KRY_SEG / 2)      // double2 elements of a plane segment handled per block and plane
 #define LW 132                 // LDS row pitch: col 1 = left halo, 2..129 = tile, 130 = right halo
 
 // ---------------------------------------------------------------------------
@@ -405,11 +405,10 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // i = mx is overwritten by either face type before anything reads it,
 // BoundaryHandler.C:444-460); its boundary treatment and the boundary-plane terms
 // of the dot products follow in g_bc and k_surf.
-#ifndef KRY_FUSED_MINW
-#define KRY_FUSED_MINW 1     // waves per SIMD the 8-row field-coefficient tiles are compiled for
-#endif
+// (Compiled for the register budget the code wants -- 2 blocks per CU for the field-coefficient
+// tiles.  Forcing 3 or 4 blocks per CU through __launch_bounds__ ran 3-25 % slower at 512^3.)
 template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN>
-__global__ __launch_bounds__(NT, (TY == 8 && VAR && !OFFD) ? KRY_FUSED_MINW : 1) void k_fused(const KryFused a)
+__global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 {
 	constexpr int VD = TY / NW;                 // rows per thread
 	constexpr int ND = KindTraits<KIND>::ND;
