@@ -1,0 +1,158 @@
+// Which part of k_final's structure costs bandwidth?  A stand-alone 8-read / 3-write streaming
+// kernel over 11 arrays of ~512^3 doubles with k_final's features switched on one at a time:
+//   F_SCAL   scalars and a `done` flag fetched from a device struct before anything else
+//   F_MATH   k_final<2>'s arithmetic (instead of one multiply-add per loaded value)
+//   F_RED    two dot products, block reduction, partial sums, ticket, last-block finish
+//   F_LATE   (with F_SCAL) the loads are issued before the scalars are waited for
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/finalbench.hip -o tools/finalbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+#define NT 256
+#define UN 4
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ inline d2 ldnt(const double* p) { return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p)); }
+__device__ inline void stnt(double* p, d2 v) { __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p)); }
+
+struct State { double c[12]; int done; int pad; double sums[8]; };
+struct Args { const double* r[8]; double* w[3]; State* S; double* partial; unsigned* counter; long n2; };
+
+__device__ inline double wave_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; }
+
+template <bool F_SCAL, bool F_MATH, bool F_RED, bool F_LATE>
+__global__ __launch_bounds__(NT) void k(const Args a)
+{
+	double c[12];
+	if (F_SCAL && !F_LATE) {
+		if (a.S->done) return;
+#pragma unroll
+		for (int i = 0; i < 12; ++i) c[i] = a.S->c[i];
+	} else if (!F_SCAL) {
+#pragma unroll
+		for (int i = 0; i < 12; ++i) c[i] = 1.0001 + i;
+	}
+	double acc0 = 0., acc1 = 0.;
+	const long q0 = (long)blockIdx.x * NT * UN + threadIdx.x;
+	d2 v[UN][8];
+#pragma unroll
+	for (int u = 0; u < UN; ++u) {
+		const long q = q0 + u * NT;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) v[u][i] = ldnt(a.r[i] + 2 * q);
+	}
+	if (F_SCAL && F_LATE) {
+		if (a.S->done) return;
+#pragma unroll
+		for (int i = 0; i < 12; ++i) c[i] = a.S->c[i];
+	}
+#pragma unroll
+	for (int u = 0; u < UN; ++u) {
+		const long q = q0 + u * NT;
+		if (q < a.n2) {
+			d2 o0, o1, o2;
+			if (F_MATH) {
+				// the statement sequence of k_final<2>: r0,r1,r2,u0,rt,u1,u2,phi = v[0..7]
+				d2 r2 = v[u][2] + v[u][1] * c[0];
+				d2 ph = v[u][7] + v[u][3] * c[1];
+				d2 u0 = v[u][0] + v[u][3] * c[2];
+				d2 r0 = v[u][0] + v[u][5] * c[3];
+				d2 un = u0 + v[u][6] * c[4];
+				un = un + v[u][5] * c[5];
+				ph = ph + u0 * c[6];
+				ph = ph + r0 * c[7];
+				d2 rn = r0 + r2 * c[8];
+				ph = ph + v[u][1] * c[9];
+				rn = rn + v[u][1] * c[10];
+				o0 = ph; o1 = rn; o2 = un;
+				acc0 += rn.x * rn.x; acc0 += rn.y * rn.y;
+				acc1 += rn.x * v[u][4].x; acc1 += rn.y * v[u][4].y;
+			} else {
+				d2 s = {0., 0.};
+#pragma unroll
+				for (int i = 0; i < 8; ++i) s += v[u][i] * c[i];
+				o0 = o1 = o2 = s;
+				acc0 += s.x;
+			}
+			stnt(a.w[0] + 2 * q, o0); stnt(a.w[1] + 2 * q, o1); stnt(a.w[2] + 2 * q, o2);
+		}
+	}
+	if (F_RED) {
+		__shared__ double red[4][2];
+		__shared__ int is_last;
+		const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+		double s0 = wave_sum(acc0), s1 = wave_sum(acc1);
+		if (lane == 0) { red[w][0] = s0; red[w][1] = s1; }
+		__syncthreads();
+		if (tid < 2) {
+			double t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+			__hip_atomic_store(&a.partial[(long)blockIdx.x * 2 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tid == 0) {
+			unsigned t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			is_last = (t == gridDim.x - 1);
+		}
+		__syncthreads();
+		if (!is_last) return;
+		if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+		__syncthreads();
+		double t0 = 0., t1 = 0.;
+		for (int b = tid; b < (int)gridDim.x; b += NT) { t0 += a.partial[2L * b]; t1 += a.partial[2L * b + 1]; }
+		t0 = wave_sum(t0); t1 = wave_sum(t1);
+		if (lane == 0) { red[w][0] = t0; red[w][1] = t1; }
+		__syncthreads();
+		if (tid == 0) {
+			a.S->sums[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+			a.S->sums[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+			__hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	} else if (acc0 == 123.456 && acc1 == 1.) {
+		a.S->sums[0] = acc0;
+	}
+}
+
+template <bool A, bool B, bool C, bool D>
+void run(const Args& a, long n, const char* name)
+{
+	const long n2 = n / 2;
+	const int nblk = (int)((n2 + NT * UN - 1) / (NT * UN));
+	hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<A, B, C, D>), dim3(nblk), dim3(NT), 0, 0, a);
+	CHECK(hipEventRecord(e0, 0));
+	const int reps = 10;
+	for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<A, B, C, D>), dim3(nblk), dim3(NT), 0, 0, a);
+	CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+	float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+	printf("%-52s blocks=%d : %8.1f GB/s\n", name, nblk, 11.0 * n * 8 * reps / (ms * 1e-3) / 1e9);
+}
+
+int main(int argc, char** argv)
+{
+	long n = (argc > 1) ? atol(argv[1]) : 136000000L;
+	n &= ~2047L;
+	Args a;
+	std::vector<double*> bufs(8);
+	for (auto& b : bufs) { CHECK(hipMalloc(&b, n * sizeof(double) + 4096)); CHECK(hipMemset(b, 0, n * sizeof(double))); }
+	for (int i = 0; i < 8; ++i) a.r[i] = bufs[i];
+	a.w[0] = bufs[7]; a.w[1] = bufs[0]; a.w[2] = bufs[3];     // in place, as k_final: phi, r0, u0
+	State h = {};
+	for (int i = 0; i < 12; ++i) h.c[i] = 1e-3 * (i + 1);
+	CHECK(hipMalloc(&a.S, sizeof(State))); CHECK(hipMemcpy(a.S, &h, sizeof h, hipMemcpyHostToDevice));
+	CHECK(hipMalloc(&a.partial, 2 * sizeof(double) * 1000000)); CHECK(hipMalloc(&a.counter, 64)); CHECK(hipMemset(a.counter, 0, 64));
+	a.n2 = n / 2;
+	for (int rep = 0; rep < 2; ++rep) {
+		run<false, false, false, false>(a, n, "plain 8R3W in place, non-temporal");
+		run<true, false, false, false>(a, n, "+ scalars/done from a device struct first");
+		run<true, false, false, true>(a, n, "+ scalars/done, loads issued before they are needed");
+		run<false, true, false, false>(a, n, "+ k_final arithmetic");
+		run<false, false, true, false>(a, n, "+ block reduction, ticket");
+		run<true, true, true, false>(a, n, "all three (k_final as built)");
+		run<true, true, true, true>(a, n, "all three, loads issued before the scalars");
+	}
+	return 0;
+}
