@@ -101,6 +101,8 @@ typedef struct kry_stats {
 	double comm_wait_ms[2];
 	int    comm_wait_calls[2];   /* timed transport calls (0 on the mapped-memory routes) */
 	int    rccl_ranks;       /* ranks of the RCCL communicator (ncclCommCount), 0: none in use */
+	int    staged_fields;    /* fields copied into the library for the last solve: 3 or 6-7 after a load /
+	                            full solve, only the replaced ones after kry_update_* + kry_resolve */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;
@@ -205,6 +207,23 @@ int kry_load_var(kry_handle h, const double *phi, const double *rhs, const doubl
                  int use_offdiag);
 int kry_iterate(kry_handle h, int n_outer);
 int kry_fetch_phi(kry_handle h, double *phi);
+
+/* Repeated solves with the coefficients resident on the device: what a time-stepping caller of
+ * Linsolver3D::solve does next (BICGStab3D/LinSolver3D.hpp:31-46 carries delt / evolve_time for
+ * it; BiCGStab3D_CL/BiCGStabCL.hpp:44 names the host code).  After a kry_load_* or kry_solve_*
+ * the operator (D fields or constants, lambda) stays in HBM;
+ *   kry_update_rhs / _phi / _lambda  replace one field (host or device pointer, host layout);
+ *   kry_reset    re-runs the prologue of solve_int (solveLin_BICGStab.C:268-320: norm of rhs,
+ *                first residual, r~, zeroed work vectors) on the resident fields, after which
+ *                kry_iterate steps as usual;
+ *   kry_resolve  = kry_reset + iterate to convergence [+ copy the solution to phi unless NULL].
+ * A solve through kry_update_* + kry_resolve gives the bits of kry_solve_* on the same fields.
+ * kry_stats.staged_fields counts the fields that crossed into the library for the last solve. */
+int kry_update_rhs(kry_handle h, const double *rhs);
+int kry_update_phi(kry_handle h, const double *phi);
+int kry_update_lambda(kry_handle h, const double *lambda);
+int kry_reset(kry_handle h);
+int kry_resolve(kry_handle h, double *phi, int debug);
 
 /* Per-kernel timing (HIP events around every launch of the fused path, accumulated in
  * kry_stats.kernel_ms / kernel_calls) on or off from the next kry_iterate on; the start value

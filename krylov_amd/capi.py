@@ -27,6 +27,7 @@ SYMBOLS = [
     "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks", "kry_device_check",
     "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
+    "kry_update_rhs", "kry_update_phi", "kry_update_lambda", "kry_reset", "kry_resolve",
     "kry_set_profile", "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_op_dot_static", "kry_status_string", "kry_last_error",
 ]
@@ -70,6 +71,7 @@ class KryStats(C.Structure):
         ("comm_wait_ms", C.c_double * 2),
         ("comm_wait_calls", C.c_int * 2),
         ("rccl_ranks", C.c_int),
+        ("staged_fields", C.c_int),
     ]
 
 
@@ -130,6 +132,13 @@ def lib():
     L.kry_load_const.argtypes = [vp, _dp, _dp, _dp, cd, cd, cd]
     L.kry_load_var.restype = ci
     L.kry_load_var.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, vp, ci]
+    for name in ("kry_update_rhs", "kry_update_phi", "kry_update_lambda"):
+        getattr(L, name).restype = ci
+        getattr(L, name).argtypes = [vp, _dp]
+    L.kry_reset.restype = ci
+    L.kry_reset.argtypes = [vp]
+    L.kry_resolve.restype = ci
+    L.kry_resolve.argtypes = [vp, vp, ci]
     L.kry_iterate.restype = ci
     L.kry_iterate.argtypes = [vp, ci]
     L.kry_fetch_phi.restype = ci
@@ -304,6 +313,22 @@ class Solver:
     def load_var(self, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy=None, use_offdiag=False):
         return _check(lib().kry_load_var(self._h, phi, rhs, lam, Dxx, Dyy, Dzz, _ptr(Dxy),
                                          int(use_offdiag)), "kry_load_var")
+
+    def update_rhs(self, rhs):
+        return _check(lib().kry_update_rhs(self._h, rhs), "kry_update_rhs")
+
+    def update_phi(self, phi):
+        return _check(lib().kry_update_phi(self._h, phi), "kry_update_phi")
+
+    def update_lambda(self, lam):
+        return _check(lib().kry_update_lambda(self._h, lam), "kry_update_lambda")
+
+    def reset(self):
+        return _check(lib().kry_reset(self._h), "kry_reset")
+
+    def resolve(self, phi=None, debug=0):
+        """Prologue + iteration to convergence on the resident fields; phi (optional) receives the solution."""
+        return _check(lib().kry_resolve(self._h, _ptr(phi), debug), "kry_resolve")
 
     def iterate(self, n):
         return _check(lib().kry_iterate(self._h, int(n)), "kry_iterate")

@@ -100,6 +100,36 @@ int compat_solve3(const int mx[3], int L, double eps, double *phi, const double 
 	return s.iterations();
 }
 
+// `steps` solves in a row through one BICGStab object, the right-hand side scaled by (1 + step) each
+// time and phi restarted from `phi0` -- the shape of a time-stepping caller.  keep != 0: coefficients
+// stay on the device between the solves.  out_iters / out_staged: per step.
+int compat_time_steps(const int mx[3], int L, double eps, int steps, int keep, const double *phi0, double *phi,
+                      const double *rhs0, const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
+                      int *out_iters, int *out_staged)
+{
+	grid_1D gx(0, 1, mx[0] + 1, 2, 0, true), gy(0, 1, mx[1] + 1, 2, 0, true), gz(0, 1, mx[2] + 1, 2, 0, true);
+	BoundaryHandler3D b;
+	b.set_bcType(0);
+	NumMatrix<double, 3> mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy;
+	wrap(mphi, mx, phi0); wrap(mrhs, mx, rhs0); wrap(mlam, mx, lam);
+	wrap(mDxx, mx, Dxx); wrap(mDyy, mx, Dyy); wrap(mDzz, mx, Dzz); wrap(mDxy, mx, NULL);
+	BICGStab s;
+	s.set_KeepCoefficients(keep != 0);
+	Linsolver3D *ls = &s;
+	NumArray<int> pars(1);
+	pars(0) = L;
+	ls->setup(gx, gy, gz, eps, pars, true, false, 0);
+	for (int t = 0; t < steps; ++t) {
+		memcpy(mphi.data(), phi0, mphi.size() * sizeof(double));
+		for (size_t i = 0; i < mrhs.size(); ++i) mrhs.data()[i] = rhs0[i] * (1. + t);
+		ls->solve(b, mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy, 0, false, 0.1, true);
+		out_iters[t] = s.iterations();
+		out_staged[t] = s.stagedFields();
+		memcpy(phi + (size_t)t * mphi.size(), mphi.data(), mphi.size() * sizeof(double));
+	}
+	return 0;
+}
+
 // the construction style of the reference's OpenCL solver (BiCGStab3D_CL/main.cpp:410-412, 532-540):
 // constant-coefficient solve on Dirichlet faces; out = {iterations, steptimeMin, steptimeMax, number of step times,
 // sum of the unrounded step times in ms}

@@ -210,6 +210,7 @@ void BICGStab::finish(int st)
 	n_iter = s.iterations;
 	last_status = st;
 	fused = s.fused != 0;
+	staged_fields = s.staged_fields;
 	norm_final = s.norm_final;
 	norm_rhs = s.norm_rhs;
 	solve_ms = s.solve_ms;
@@ -298,10 +299,25 @@ void BICGStab::solve_int(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, N
                          NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug_)
 {
 	// BICGStab3D/solveLin_BICGStab.C:250-527 runs on the device
+	kry_solver *before = handle;
 	ensure_handle(bounds, phi);
 	int st;
-	if (use_spatialDiffusion) {
-		const double *dxy = (use_offDiagDiffusion && Dxy.size() > 0) ? Dxy.data() : NULL;
+	const double *dxy = (use_spatialDiffusion && use_offDiagDiffusion && Dxy.size() > 0) ? Dxy.data() : NULL;
+	const int mode = use_spatialDiffusion ? (dxy ? 2 : 1) : 0;
+	const void *coef[5] = {lambda.data(), use_spatialDiffusion ? Dxx.data() : NULL, use_spatialDiffusion ? Dyy.data() : NULL,
+	                       use_spatialDiffusion ? Dzz.data() : NULL, dxy};
+	bool same = keep_coefficients && handle == before && before != NULL && mode == last_mode;
+	for (int k = 0; k < 5; ++k) same = same && coef[k] == last_coef[k];
+	if (mode == 0) for (int k = 0; k < 3; ++k) same = same && DiffDiag[k] == last_diag[k];
+	for (int k = 0; k < 5; ++k) last_coef[k] = coef[k];
+	for (int k = 0; k < 3; ++k) last_diag[k] = DiffDiag[k];
+	last_mode = mode;
+	if (same) {
+		// the operator is on the device already: stage phi and rhs, re-run the prologue, solve
+		st = kry_update_phi(handle, phi.data());
+		if (st >= 0) st = kry_update_rhs(handle, rhs.data());
+		if (st >= 0) st = kry_resolve(handle, phi.data(), debug_);
+	} else if (use_spatialDiffusion) {
 		st = kry_solve_var(handle, phi.data(), rhs.data(), lambda.data(), Dxx.data(), Dyy.data(), Dzz.data(), dxy,
 		                   dxy != NULL, debug_);
 	} else {

@@ -117,6 +117,7 @@ struct kry_solver {
 	int n_ranks() const { return np[0] * np[1] * np[2]; }
 	bool var = false, offd = false;
 	bool loaded = false;
+	bool reset_needed = false;  // a field was replaced (kry_update_*) and the prologue has not run since
 	KryOp op;
 	int ty = 8, zc = 16;
 	bool zc_fixed = false;     // KRY_ZC given: no automatic choice
@@ -129,6 +130,8 @@ struct kry_solver {
 	bool done = false;
 	double norm_rhs = 0, norm_init = 0, norm_final = 0;
 	double solve_ms = 0, stage_ms = 0;
+	double pending_stage_ms = 0;   // staging done by kry_update_* since the last solve
+	int staged_fields = 0;         // field copies into the library for the current / last solve
 	double enqueue_ms = 0;     // host time spent queueing the passes of the last run
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
 	// two consecutive passes (even, odd: the ping-pong buffers swap roles) captured as a
@@ -202,6 +205,7 @@ void drop_stage(Slab &s)
 int upload(kry_solver *h, Slab &s, int local_idx, Field &f, const double *host)
 {
 	HIPCHK(hipSetDevice(s.device));
+	if (local_idx == 0) h->staged_fields += 1;
 	const int mxh = h->d.mx[0], myh = h->d.mx[1];
 	const size_t hrow = (size_t)(mxh + 3);
 	const double *src = host + (size_t)local_idx * h->mzl * hrow * (myh + 3);
@@ -1188,6 +1192,7 @@ int build_graph(kry_solver *h)
 int run_iterations(kry_solver *h, int n_outer)
 {
 	if (!h->loaded) { set_err("kry_iterate: no problem loaded"); return KRY_ERR_STATE; }
+	if (h->reset_needed) { set_err("kry_iterate: fields were replaced, call kry_reset or kry_resolve first"); return KRY_ERR_STATE; }
 	if (h->done) return h->status;
 	hipEvent_t e0, e1;
 	Slab &s0 = h->slabs[0];
@@ -1304,6 +1309,8 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	}
 	double t0 = now_ms();
 	drop_graph(h);
+	h->staged_fields = 0;
+	h->pending_stage_ms = 0;
 	h->var = var;
 	h->offd = var && offd;
 	make_op(h, var, Dc);
@@ -1332,6 +1339,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 		}
 	}
 	h->loaded = true;
+	h->reset_needed = false;
 	for (int k = 8; k < 10; ++k) { h->kernel_ms[k] = 0; h->kernel_calls[k] = 0; }
 	h->solve_ms = 0;
 	h->enqueue_ms = 0;
@@ -1769,6 +1777,64 @@ int kry_load_var(kry_handle h, const double *phi, const double *rhs, const doubl
 	return load_common(h, true, use_offdiag != 0, Dc, phi, rhs, lambda, Dxx, Dyy, Dzz, Dxy);
 }
 
+static int solve_tail(kry_handle h, double *phi, int debug);
+
+// ---- resident re-solves: the coefficients stay on the device -------------------
+
+static int update_field(kry_handle h, const char *who, Field Slab::*f, const double *src, bool exchange)
+{
+	if (!h || !src) { set_err("%s: null argument", who); return KRY_ERR_ARG; }
+	if (!h->loaded) { set_err("%s: no problem loaded", who); return KRY_ERR_STATE; }
+	const double t0 = now_ms();
+	if (h->done || h->it_base > 0) { h->staged_fields = 0; h->done = false; h->it_base = 0; }   // first update after a solve
+	h->reset_needed = true;
+	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(upload(h, h->slabs[i], (int)i, h->slabs[i].*f, src));
+	if (exchange && (h->slabs.size() > 1 || h->comm.active())) {
+		auto v = ptrs(h, f);
+		CHK(exchange_halo(h, v));
+	}
+	CHK(sync_all(h));
+	for (Slab &s : h->slabs) drop_stage(s);
+	h->pending_stage_ms += now_ms() - t0;
+	return KRY_OK;
+}
+
+int kry_update_rhs(kry_handle h, const double *rhs) { return update_field(h, "kry_update_rhs", &Slab::rhs, rhs, false); }
+int kry_update_phi(kry_handle h, const double *phi) { return update_field(h, "kry_update_phi", &Slab::phi, phi, true); }
+int kry_update_lambda(kry_handle h, const double *lambda)
+{
+	return update_field(h, "kry_update_lambda", &Slab::lam, lambda, false);
+}
+
+int kry_reset(kry_handle h)
+{
+	if (!h) return KRY_ERR_ARG;
+	if (!h->loaded) { set_err("kry_reset: no problem loaded"); return KRY_ERR_STATE; }
+	const double t0 = now_ms();
+	h->solve_ms = 0;
+	h->enqueue_ms = 0;
+	for (int k = 8; k < 10; ++k) { h->kernel_ms[k] = 0; h->kernel_calls[k] = 0; }
+	CHK(prologue(h));
+	CHK(sync_all(h));
+	h->reset_needed = false;
+	h->stage_ms = h->pending_stage_ms + (now_ms() - t0);
+	h->pending_stage_ms = 0;
+	return h->status;
+}
+
+int kry_resolve(kry_handle h, double *phi, int debug)
+{
+	if (!h) return KRY_ERR_ARG;
+	h->debug = debug;
+	int st = kry_reset(h);
+	if (st < 0) return st;
+	if (!phi) {
+		if (st == 0 && !h->done) st = run_iterations(h, 0);
+		return st;
+	}
+	return solve_tail(h, phi, debug);
+}
+
 int kry_iterate(kry_handle h, int n_outer)
 {
 	if (!h) return KRY_ERR_ARG;
@@ -1847,6 +1913,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 		o->comm_wait_ms[1] += h->slabs[0].Sh->wait_halo_ticks * h->tick_ms;
 	}
 	o->rccl_ranks = h->comm.rccl_ranks();
+	o->staged_fields = h->staged_fields;
 	o->tile_rows = h->gen ? 8 : h->ty;
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;
