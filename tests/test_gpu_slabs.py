@@ -131,3 +131,22 @@ def test_repeated_multi_slab_solves_are_reproducible(orc):
                 ref[ns] = r["history"]
             assert np.array_equal(r["history"], ref[ns]), (trial, ns)
     assert np.max(np.abs(ref[4] - ref[8])) <= 1e-10 * ref[4][0]
+
+
+def test_sixteen_slabs_on_one_device_with_overlapped_exchange(orc, monkeypatch):
+    """The largest slab count a process may own (KRY_MAX_SLABS = 16) on ONE device: 32 streams on
+    the device's four hardware queues, every stencil kernel launched in two parts with the
+    exchange of 15 interfaces on the second streams in between.  Every event is recorded (host
+    order) before anything waits for it, so no hardware queue can hold a wait in front of its own
+    producer; this run is the check of that argument at the largest supported size."""
+    monkeypatch.setenv("KRY_ZC", "2")
+    monkeypatch.setenv("KRY_OVERLAP", "1")
+    p = P.smooth_var((24, 20, 128))
+    p.rhs = np.random.default_rng(12).uniform(-1, 1, p.rhs.shape)
+    one = capi.solve_problem(p, L=2, eps=1e-30, max_outer=8)
+    runs = [capi.solve_problem(p, L=2, eps=1e-30, max_outer=8, nslabs_local=16, devices=(0,)) for _ in range(3)]
+    for r in runs:
+        assert r["fused"] and r["iters"] == 8
+        assert np.array_equal(r["history"], runs[0]["history"])
+        assert np.max(np.abs(r["history"] - one["history"])) <= 1e-10 * one["norm_rhs"]
+        assert rel_l2(points(r["phi"]), points(one["phi"])) <= 1e-10
