@@ -495,27 +495,64 @@ def main():
                 trial = {k: (round(v, 4) if np.isfinite(v) else None) for k, v in trial.items()}
         barrier()
 
-    t_stage = time.perf_counter()
-    load()
-    t_stage = time.perf_counter() - t_stage
+    def measure():
+        """Stage, warm up, time K passes.  Returns None when this rank's run failed."""
+        try:
+            ts = time.perf_counter()
+            load()
+            ts = time.perf_counter() - ts
+            if args.warmup > 0:
+                solver.iterate(args.warmup)
+            a = solver.stats()
+            barrier()
+            t0 = time.perf_counter()
+            stt = solver.iterate(args.steps)          # returns after a stream synchronise
+            t1 = time.perf_counter()
+            barrier()
+            return ts, a, solver.stats(), stt, t1 - t0, solver.history()
+        except capi.KryError as e:
+            sys.stderr.write("rank %d: %s\n" % (rank, e))
+            try:
+                barrier()
+                barrier()
+            except Exception:
+                pass
+            return None
 
-    st = solver.iterate(args.warmup) if args.warmup > 0 else 0
-    s0 = solver.stats()
+    def ranks_agree(m):
+        """Every rank ran, finished, and holds the same residual history bit for bit (the sums are
+        formed once and shared, or added in the same order everywhere): stale or lost exchange data
+        on any rank would break that."""
+        mine = None if m is None else (int(m[3]), m[5].tobytes())
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        return all(g is not None and g[0] == 0 and g[1] == got[0][1] for g in got)
 
-    barrier()
-    t0 = time.perf_counter()
-    st = solver.iterate(args.steps)          # returns after a stream synchronise
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = t1 - t0
+    m = measure()
+    agree = None
+    if world > 1:
+        agree = ranks_agree(m)
+        if not agree and exchange != "transport":
+            # the mapped-memory route misbehaved on this machine: measure through the transport instead
+            why = "%s was chosen by the trial but the ranks' histories disagreed in the timed run; transport used" % exchange
+            exchange = "transport"
+            solver.mail_enable(0)
+            barrier()
+            m = measure()
+            agree = ranks_agree(m)
+    if m is None or agree is False:
+        # (a collective decision: `agree` is the same on every rank)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"metric": METRIC, "value": None, "unit": "iter/s", "n_gpus": world,
+                                               "valid": False, "error": "the timed run failed on a rank, or the ranks' residual histories differ",
+                                               "config": {"transport": transport, "exchange": exchange}}) + "\n").encode())
+        return 1
+    t_stage, s0, s1, st, elapsed, hist = m
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-
-    s1 = solver.stats()
-    hist = solver.history()
-    ok = (st == 0 and s1.iterations == args.warmup + args.steps and np.all(np.isfinite(hist)))
+    ok = (st == 0 and s1.iterations == args.warmup + args.steps and np.all(np.isfinite(hist)) and agree is not False)
 
     # Several GPUs: the timed region runs without per-kernel events (rank 0 would lag behind the
     # others by their cost); the kernel table, the roofline and the transport's share of a pass
@@ -591,7 +628,8 @@ def main():
                        "devices_visible": ndev, "ranks_per_device": -(-world // ndev),
                        "transport": transport, "rccl_ranks": rccl["ranks"], "rccl_error": rccl["error"],
                        "exchange": exchange, "exchange_reason": why,
-                       "exchange_trial_ms_per_pass": trial, "wait_share_of_pass": wait},
+                       "exchange_trial_ms_per_pass": trial, "wait_share_of_pass": wait,
+                       "ranks_hold_identical_history": agree},
             "valid": bool(ok), "solver_path": s1.fused,
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),

@@ -10,7 +10,8 @@ import json
 import sys
 
 NAMES = {"k_fused<0": "fused_A0", "k_fused<2": "fused_B0", "k_fused<1": "fused_A1", "k_fused<3": "fused_B0L",
-         "k_fused<4": "fused_B1L", "k_mgs2": "mgs2", "k_final<": "final", "k_fused<5": "fused_residual"}
+         "k_fused<4": "fused_B1L", "k_mgs2": "mgs2", "k_final<": "final", "k_fused<5": "fused_residual",
+         "g_bc": "bc_faces", "k_surf<": "surface"}
 
 
 def agg(path):
