@@ -128,9 +128,32 @@ std::string entry_attr_name(int n)
 
 // ------------------------------------------------------------------ writer
 
-Hdf5Stream::Hdf5Stream(std::string filename, int NumEntries, int, bool)
+Hdf5Stream::Hdf5Stream(std::string filename, int NumEntries, int, bool use_MPI_IO_
+#ifdef parallel
+                       , MPI_Comm comm_
+#endif
+                       )
     : filename(filename), NumEntries(NumEntries), num(0), open(true)
 {
+#ifdef parallel
+	comm = comm_;
+	use_MPI_IO = use_MPI_IO_;
+	comm_rank = 0;
+	comm_size = 1;
+	if (use_MPI_IO) {
+		MPI_Comm_rank(comm, &comm_rank);
+		MPI_Comm_size(comm, &comm_size);
+	}
+	if (!on_disk()) {
+		// not the owner of the shared file: the same calls work on a file that lives in memory only
+		hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
+		H5Pset_fapl_core(fapl, 1 << 20, 0);
+		hdf5file = H5Fcreate(filename.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
+		H5Pclose(fapl);
+	} else
+#else
+	(void)use_MPI_IO_;
+#endif
 	hdf5file = H5Fcreate(filename.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
 	group = H5Gcreate2(hdf5file, "/Data", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
 	const int one = 1;
@@ -164,6 +187,21 @@ bool Hdf5Stream::close()
 void Hdf5Stream::Reopen()
 {
 	if (open) return;
+#ifdef parallel
+	if (!on_disk()) {
+		// the memory-only file of a non-owner is gone with close(): start a fresh one
+		hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
+		H5Pset_fapl_core(fapl, 1 << 20, 0);
+		hdf5file = H5Fcreate(filename.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
+		H5Pclose(fapl);
+		group = H5Gcreate2(hdf5file, "/Data", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+		Space sp(H5Screate(H5S_SCALAR));
+		Attr a(H5Acreate2(group, "Entries", H5T_NATIVE_INT, sp, H5P_DEFAULT, H5P_DEFAULT));
+		H5Awrite(a, H5T_NATIVE_INT, &num);
+		open = true;
+		return;
+	}
+#endif
 	hdf5file = H5Fopen(filename.c_str(), H5F_ACC_RDWR, H5P_DEFAULT);
 	group = H5Gopen2(hdf5file, "Data", H5P_DEFAULT);
 	open = true;
@@ -235,6 +273,73 @@ bool Hdf5Stream::Write3DMatrix(std::string ArrayName, NumMatrix<float, 3> &data)
 {
 	return Write3DMatrix(ArrayName, data, nullptr, nullptr, false);
 }
+
+#ifdef parallel
+bool Hdf5Stream::Write3DMatrix_withMPI_IO(std::string ArrayName, NumMatrix<float, 3> &data, NumArray<int> &mx_global,
+                                          NumArray<int> &mx_local, NumArray<int> &rank_shift, NumArray<float> &xb,
+                                          NumArray<float> &dx, bool with_opendxinfo)
+{
+	// BICGStab3D/Hdf5File_cbase.C:1241-1365
+	const int rim = data.getLow(0) < 0 ? -data.getLow(0) : 0;
+	AddDatasetName(ArrayName);
+	num += 1;
+	if (!use_MPI_IO) {
+		std::cerr << " Write3DMatrix_withMPI_IO: the stream was opened without use_MPI_IO" << std::endl;
+		return false;
+	}
+	// block geometry in file order (slowest index first), gathered on the owner
+	int geo[6];
+	for (int q = 0; q < 3; ++q) {
+		geo[q] = mx_local[2 - q] + 1 + 2 * rim;
+		geo[3 + q] = rank_shift[2 - q];
+	}
+	std::vector<int> all(on_disk() ? 6 * comm_size : 0);
+	MPI_Gather(geo, 6, MPI_INT, all.data(), 6, MPI_INT, 0, comm);
+	const long count = (long)geo[0] * geo[1] * geo[2];
+	if ((long)data.size() != count) {
+		std::cerr << " Write3DMatrix_withMPI_IO: the field's extents do not match mx_local and its rim" << std::endl;
+		return false;
+	}
+	bool ok = true;
+	if (!on_disk()) {
+		MPI_Send(data.data(), (int)count, MPI_FLOAT, 0, 4711, comm);
+	} else {
+		hsize_t dims[3];
+		for (int q = 0; q < 3; ++q) dims[q] = (hsize_t)(mx_global[2 - q] + 1 + 2 * rim);
+		Type t(le_type(H5T_NATIVE_FLOAT));
+		Space file_space(H5Screate_simple(3, dims, NULL));
+		Dset ds(H5Dcreate2(group, ArrayName.c_str(), t, file_space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));
+		if (ds < 0) ok = false;
+		if (ok && with_opendxinfo) {
+			float origin[3], delta[3];
+			for (int q = 0; q < 3; ++q) { origin[q] = xb[q]; delta[q] = dx[q]; }
+			ok = put_attr(ds, "origin", H5T_NATIVE_FLOAT, origin, 3) && put_attr(ds, "delta", H5T_NATIVE_FLOAT, delta, 3);
+		}
+		std::vector<float> buf;
+		for (int r = 0; r < comm_size; ++r) {
+			const int *g = &all[6 * r];
+			const long n = (long)g[0] * g[1] * g[2];
+			const float *src = data.data();
+			if (r != 0) {
+				buf.resize((size_t)n);
+				MPI_Recv(buf.data(), (int)n, MPI_FLOAT, r, 4711, comm, MPI_STATUS_IGNORE);
+				src = buf.data();
+			}
+			hsize_t size[3], off[3];
+			for (int q = 0; q < 3; ++q) { size[q] = (hsize_t)g[q]; off[q] = (hsize_t)g[3 + q]; }
+			if (!ok) continue;                      // keep receiving so that no sender is left waiting
+			for (int q = 0; q < 3; ++q) ok = ok && off[q] + size[q] <= dims[q];
+			if (!ok) continue;
+			Space mem(H5Screate_simple(3, size, NULL));
+			ok = H5Sselect_hyperslab(file_space, H5S_SELECT_SET, off, NULL, size, NULL) >= 0 &&
+			     H5Dwrite(ds, t, mem, file_space, H5P_DEFAULT, src) >= 0;
+		}
+	}
+	int mine = ok ? 1 : 0, every = 0;
+	MPI_Allreduce(&mine, &every, 1, MPI_INT, MPI_MIN, comm);
+	return every == 1;
+}
+#endif
 
 bool Hdf5Stream::Write3DMatrixSwap(std::string ArrayName, NumMatrix<double, 3> &data, double *xb, double *dx)
 {

@@ -120,3 +120,26 @@ def test_layout_on_disk(written):
 
     assert values("/Data/phi", x) == list(phi[0, 0, :])
     assert values("/Data/phi_T", z) == list(phi[:, 0, 0])
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+H5_MPI_SELFTEST = os.path.join(ROOT, "krylov_amd", "driver", "compat_h5_mpi_selftest")
+
+
+@pytest.mark.parametrize("nproc", [(1, 1, 2), (2, 2, 2)])
+def test_one_file_for_all_processes(tmp_path, nproc):
+    """Hdf5Stream(..., use_MPI_IO = true, comm) + Write3DMatrix_withMPI_IO
+    (BICGStab3D/Hdf5File_cbase.H:18-26, 64-72; .C:1241-1365) under mpiexec: every process of the
+    reference's Cartesian split writes its block, ghost layers included, into one dataset of the
+    global extent; the program reads it back and checks every value against the global position
+    it encodes.  Here h5dump checks the layout."""
+    if not (os.path.exists(MPIEXEC) and os.path.exists(H5_MPI_SELFTEST)):
+        pytest.skip("no MPI installation / parallel flavour not built")
+    path = str(tmp_path / "all.h5")
+    n = nproc[0] * nproc[1] * nproc[2]
+    out = subprocess.run([MPIEXEC, "-n", str(n), H5_MPI_SELFTEST, path] + [str(v) for v in nproc], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout + out.stderr
+    head = subprocess.run([H5DUMP, "-H", path], capture_output=True, text=True).stdout
+    assert re.search(r'DATASET "rho" \{\s*DATATYPE\s+H5T_IEEE_F32LE\s*DATASPACE\s+SIMPLE \{ \( 19, 19, 19 \)', head)
+    assert 'ATTRIBUTE "origin"' in head and 'DATASET "rho2"' in head and 'ATTRIBUTE "Name_om01"' in head

@@ -137,7 +137,14 @@ int main(int argc, char** argv)
 	n &= ~2047L;
 	Args a;
 	std::vector<double*> bufs(8);
-	for (auto& b : bufs) { CHECK(hipMalloc(&b, n * sizeof(double) + 4096)); CHECK(hipMemset(b, 0, n * sizeof(double))); }
+	// FINALBENCH_SHIFT=<bytes>: every array starts that many bytes behind its allocation (alignment of the
+	// 1 KiB wave loads and 16 KiB block segments against the memory system's granules)
+	const long shift = getenv("FINALBENCH_SHIFT") ? atol(getenv("FINALBENCH_SHIFT")) : 0;
+	for (auto& b : bufs) {
+		CHECK(hipMalloc(&b, n * sizeof(double) + 65536)); CHECK(hipMemset(b, 0, n * sizeof(double) + 65536));
+		b = (double*)((char*)b + shift);
+	}
+	printf("shift %ld bytes\n", shift);
 	for (int i = 0; i < 8; ++i) a.r[i] = bufs[i];
 	a.w[0] = bufs[7]; a.w[1] = bufs[0]; a.w[2] = bufs[3];     // in place, as k_final: phi, r0, u0
 	State h = {};
@@ -145,7 +152,7 @@ int main(int argc, char** argv)
 	CHECK(hipMalloc(&a.S, sizeof(State))); CHECK(hipMemcpy(a.S, &h, sizeof h, hipMemcpyHostToDevice));
 	CHECK(hipMalloc(&a.partial, 2 * sizeof(double) * 1000000)); CHECK(hipMalloc(&a.counter, 64)); CHECK(hipMemset(a.counter, 0, 64));
 	a.n2 = n / 2;
-	for (int rep = 0; rep < 2; ++rep) {
+	for (int rep = 0; rep < (shift ? 1 : 2); ++rep) {
 		run<false, false, false, false>(a, n, "plain 8R3W in place, non-temporal");
 		run<true, false, false, false>(a, n, "+ scalars/done from a device struct first");
 		run<true, false, false, true>(a, n, "+ scalars/done, loads issued before they are needed");
