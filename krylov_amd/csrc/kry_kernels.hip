@@ -382,6 +382,94 @@ __device__ inline double apply_op(const Sten &s, const KryOp &op)
 	}
 }
 
+// ---------------------------------------------------------------------------
+// do_BCs on the INPUT of the constant-coefficient operator (Krylov.C:516), for the
+// fused general-boundary kernels.  The stencil input psi = X + c*Y is produced in the
+// kernel; its boundary treatment (BoundaryHandler.C:416-568: x faces, then y, then z,
+// each over the tangential range the reference gives it) makes the value of a cell in
+// the two outermost layers a fixed expression in untreated values further inside.
+// bc_psi() evaluates that expression for one cell from memory -- the same products and
+// differences, in the same order, as the sequential treatment -- so no thread needs
+// another thread's result.  Defined for the cells the 7-point operator reads (grid
+// points and the ghost cells straight behind a face); edge and corner ghosts, which
+// nothing reads, get some value of the same recursion.
+// ---------------------------------------------------------------------------
+struct PsiSrc {
+	const double *X, *Y, *Z1, *Z2;
+	double c, dz1, dz2;
+	int nz;
+};
+
+__device__ __forceinline__ double psi_raw(const PsiSrc &s, const KryGeo &g, int i, int j, int k)
+{
+	const long p = kry_idx(g, i, j, k);
+	double y = s.Y[p];
+	if (s.nz >= 1) y = axpy1(y, s.Z1[p], s.dz1);
+	if (s.nz >= 2) y = axpy1(y, s.Z2[p], s.dz2);
+	return axpy1(s.X[p], y, s.c);
+}
+
+// How do_BCs forms a cell's value along one axis: from the cell itself (P_ID), zero (P_ZERO),
+// 2 f(a) - f(b) (P_LIN), or the second extrapolated cell 2 (2 f(a) - f(b)) - f(a) (P_LIN2).
+enum { P_ID = 0, P_ZERO, P_LIN, P_LIN2 };
+struct PsiAxis {
+	int mode, a, b;
+};
+
+// index c of an axis with last point m: lower face type tlo (treated unless `nlo`: a neighbour lies
+// behind it), upper face type thi.  zlow: the lower z face also rewrites the boundary plane, from
+// planes 1 and 2 (BoundaryHandler.C:536-544); the lower x and y faces fill the ghost cell only.
+__device__ __forceinline__ PsiAxis psi_axis(int c, int m, int nlo, int nhi, int tlo, int thi, bool zlow)
+{
+	PsiAxis r = {P_ID, c, c};
+	if (!nlo && c <= 0) {
+		if (tlo == 0) r.mode = P_ZERO;
+		else if (tlo == 1 && c < 0) { r.mode = P_LIN; r.a = 0; r.b = 1; }
+		else if (tlo == 1 && zlow) { r.mode = P_LIN; r.a = 1; r.b = 2; }
+	}
+	if (!nhi && c >= m) {
+		if (thi == 0) r.mode = P_ZERO;
+		else if (thi == 1) { r.mode = (c == m) ? P_LIN : P_LIN2; r.a = m - 1; r.b = m - 2; }
+	}
+	return r;
+}
+
+__device__ __forceinline__ double psi_comb(int mode, double fa, double fb)
+{
+	double t = 2. * fa - fb;
+	if (mode == P_LIN2) t = 2. * t - fa;
+	return t;
+}
+
+// value of cell (i,j,k) after do_BCs; `v` is its untreated value (returned where no face reaches)
+__device__ __forceinline__ double bc_psi(const PsiSrc &s, const KryGeo &g, double v, int i, int j, int k)
+{
+	if (i > 0 && i < g.mx && j > 0 && j < g.my && k > 0 && k < g.mz) return v;
+	if (i < -1 || i > g.mx + 1 || j < -1 || j > g.my + 1 || k < -1 || k > g.mz + 1) return v;   // tile overshoot
+	// x faces reach over the whole tangential box, y faces over i = 0..mx, z faces over i = 0..mx, j = 0..my
+	const PsiAxis ax = psi_axis(i, g.mx, g.nb[0], g.nb[1], g.bc[0], g.bc[1], false);
+	PsiAxis ay = {P_ID, j, j}, az = {P_ID, k, k};
+	const bool in_x = (i >= 0 && i <= g.mx);
+	if (in_x) ay = psi_axis(j, g.my, g.nb[2], g.nb[3], g.bc[2], g.bc[3], false);
+	if (in_x && j >= 0 && j <= g.my) az = psi_axis(k, g.mz, g.has_lo, g.has_hi, g.bc[4], g.bc[5], true);
+	if (ax.mode == P_ZERO || ay.mode == P_ZERO || az.mode == P_ZERO) return 0.;
+	if (ax.mode == P_ID && ay.mode == P_ID && az.mode == P_ID) return v;
+	// x treatment of the untreated values, y treatment of those, z treatment of those
+	auto ex = [&](int jj, int kk) __attribute__((always_inline)) -> double {
+		const double fa = psi_raw(s, g, ax.a, jj, kk);
+		if (ax.mode == P_ID) return fa;
+		return psi_comb(ax.mode, fa, psi_raw(s, g, ax.b, jj, kk));
+	};
+	auto ey = [&](int kk) __attribute__((always_inline)) -> double {
+		const double fa = ex(ay.a, kk);
+		if (ay.mode == P_ID) return fa;
+		return psi_comb(ay.mode, fa, ex(ay.b, kk));
+	};
+	const double fa = ey(az.a);
+	if (az.mode == P_ID) return fa;
+	return psi_comb(az.mode, fa, ey(az.b));
+}
+
 template <int KIND> struct KindTraits;
 template <> struct KindTraits<KF_A0>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
 template <> struct KindTraits<KF_A1>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
@@ -407,9 +495,12 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // of the dot products follow in g_bc and k_surf.
 // (Compiled for the register budget the code wants -- 2 blocks per CU for the field-coefficient
 // tiles.  Forcing 3 or 4 blocks per CU through __launch_bounds__ ran 3-25 % slower at 512^3.)
-template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN>
+// INBC (constant coefficients on faces that are not all Dirichlet): psi is passed through
+// do_BCs before the operator reads it and before it is stored, as Krylov.C:516 does.
+template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN, bool INBC = false>
 __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 {
+	static_assert(!INBC || (GEN && !VAR && KindTraits<KIND>::UPD), "input treatment: constant-coefficient updates only");
 	constexpr int VD = TY / NW;                 // rows per thread
 	constexpr int ND = KindTraits<KIND>::ND;
 	constexpr bool UPD = KindTraits<KIND>::UPD; // psi = X + Y*c and is stored to Xout
@@ -504,8 +595,22 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 
 	auto plane = [&](int z) -> long { return (long)(z + 1) * g.ps; };
 
+	// input treatment of the constant-coefficient operator: where the untreated operands live
+	PsiSrc bsrc;
+	bsrc.X = a.X; bsrc.Y = a.Y; bsrc.Z1 = a.Z1; bsrc.Z2 = a.Z2;
+	bsrc.c = cpsi; bsrc.dz1 = dz1; bsrc.dz2 = dz2; bsrc.nz = nz;
+	int zi = 0;          // the plane whose operands were issued last
+	auto bc2 = [&](double2 v, int i, int j) __attribute__((always_inline)) -> double2 {
+		if (INBC) {
+			v.x = bc_psi(bsrc, g, v.x, i, j, zi);
+			v.y = bc_psi(bsrc, g, v.y, i + 1, j, zi);
+		}
+		return v;
+	};
+
 	// issue the loads that psi of plane z needs (own points and halo ring)
 	auto issue = [&](int z) {
+		zi = z;
 		const long pb = plane(z);
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
@@ -543,14 +648,20 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	// psi of the issued plane at the own points
 	auto own_psi = [&](double2 (&dst)[VD]) {
 #pragma unroll
-		for (int e = 0; e < VD; ++e) dst[e] = psi2(nx[e], ny[e], nz1[DEFER ? e : 0], nz2[DEFER ? e : 0]);
+		for (int e = 0; e < VD; ++e)
+			dst[e] = bc2(psi2(nx[e], ny[e], nz1[DEFER ? e : 0], nz2[DEFER ? e : 0]), ix, y0 + w * VD + e);
+	};
+	// psi of the issued plane at this lane's halo-column cell
+	auto col_psi = [&]() __attribute__((always_inline)) -> double {
+		const double v = psi1(sx, sy, sz1, sz2);
+		return INBC ? bc_psi(bsrc, g, v, ccol - 2, y0 + crr - 1, zi) : v;
 	};
 	// write psi (own + halo) of the issued plane into an LDS buffer
 	auto to_lds = [&](const double2 (&v)[VD], double *buf) {
 #pragma unroll
 		for (int e = 0; e < VD; ++e) st2(buf + lidx[e], v[e]);
-		if (hrow) st2(buf + hl, psi2(hx, hy, hz1, hz2));
-		if (hcol && (!GEN || cside < 2)) buf[cl] = psi1(sx, sy, sz1, sz2);
+		if (hrow) st2(buf + hl, bc2(psi2(hx, hy, hz1, hz2), ix, y0 + (hr ? TY : -1)));
+		if (hcol && (!GEN || cside < 2)) buf[cl] = col_psi();
 	};
 	// store psi to its ping-pong partner at interior points of plane z
 	auto store_psi = [&](const double2 (&v)[VD], int z) {
@@ -564,7 +675,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				else if (uxy) a.Xout[pb + off[e] + 1] = v[e].y;
 			}
 		}
-		if (GEN && cstore) a.Xout[pb + coff] = psi1(sx, sy, sz1, sz2);   // sx, sy, ... still hold plane z
+		if (GEN && cstore) a.Xout[pb + coff] = col_psi();   // sx, sy, ... still hold plane z
 	};
 
 	// ---- prologue: planes z0-1, z0 and the loads of z0+1 ----
@@ -1252,25 +1363,26 @@ static hipError_t launch_fused_t(const KryFused &a, bool var, bool offd, bool ex
 // general-boundary variants, 8-row tiles (constant coefficients: only where no face
 // of the global domain needs the operator's input treated, i.e. all of them Dirichlet)
 template <int KIND>
-static hipError_t launch_fused_gen_t(const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
+static hipError_t launch_fused_gen_t(const KryFused &a, bool var, bool offd, bool exact, bool inbc, hipStream_t st)
 {
 	dim3 grid(a.nblk), block(NT);
 #define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, 8, V, O, E, true>), grid, block, 0, st, a)
-	if (!var) KRY_LAUNCH(false, false, true);
+	if (!var && inbc) hipLaunchKernelGGL((k_fused<KIND, 8, false, false, true, true, true>), grid, block, 0, st, a);
+	else if (!var) KRY_LAUNCH(false, false, true);
 	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
 	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
 #undef KRY_LAUNCH
 	return hipGetLastError();
 }
 
-hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
+hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, bool inbc, hipStream_t st)
 {
 	switch (kind) {
-	case KF_A0:  return launch_fused_gen_t<KF_A0>(a, var, offd, exact, st);
-	case KF_A1:  return launch_fused_gen_t<KF_A1>(a, var, offd, exact, st);
-	case KF_B0:  return launch_fused_gen_t<KF_B0>(a, var, offd, exact, st);
-	case KF_B0L: return launch_fused_gen_t<KF_B0L>(a, var, offd, exact, st);
-	case KF_B1L: return launch_fused_gen_t<KF_B1L>(a, var, offd, exact, st);
+	case KF_A0:  return launch_fused_gen_t<KF_A0>(a, var, offd, exact, inbc, st);
+	case KF_A1:  return launch_fused_gen_t<KF_A1>(a, var, offd, exact, inbc, st);
+	case KF_B0:  return launch_fused_gen_t<KF_B0>(a, var, offd, exact, inbc, st);
+	case KF_B0L: return launch_fused_gen_t<KF_B0L>(a, var, offd, exact, inbc, st);
+	case KF_B1L: return launch_fused_gen_t<KF_B1L>(a, var, offd, exact, inbc, st);
 	}
 	return hipErrorInvalidValue;
 }

@@ -107,7 +107,8 @@ struct kry_solver {
 	int L = 1;
 	int mzl = 0;               // slab-local mz
 	bool fused = false;        // fused path in use (device-resident recurrences)
-	bool gen = false;          // its general-boundary variant (any face types, field coefficients)
+	bool gen = false;          // its general-boundary variant (any face types)
+	bool inbc = false;         // ... with the operator's input passed through do_BCs (constant coefficients, Krylov.C:516)
 	// Cartesian split of the global domain over processes (mpi_manager.C:56-305): np
 	// sub-domains per direction, this process at co.  {1,1,nslabs} for plain z slabs.
 	int np[3] = {1, 1, 1}, co[3] = {0, 0, 0};
@@ -557,7 +558,7 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 {
 	HIPCHK(hipSetDevice(s.device));
 	if (prof & 1) prof_begin(h, s, kind);
-	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
+	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->var, h->offd, h->op.exact_rcp != 0, h->inbc, s.st));
 	else HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 	if (prof & 2) prof_end(h, s);
 	return 0;
@@ -1317,15 +1318,16 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	bool dirichlet = true;
 	for (int f = 0; f < 6; ++f) dirichlet = dirichlet && (h->d.bc_type[f] == 0);
 	// Dirichlet faces: fused kernels that keep the zero boundary implicit.  Other
-	// face types: their general-boundary variant, for field coefficients only (the
-	// constant-coefficient operator re-applies the boundary treatment to its INPUT,
-	// Krylov.C:516, which cannot be folded into the producing update).
+	// face types: their general-boundary variant; with constant coefficients the
+	// operator re-applies the boundary treatment to its INPUT (Krylov.C:516), which
+	// that variant evaluates cell by cell while it forms the input (`inbc`).
 	// A split in x or y runs the general-boundary variant too: its ghost-cell handling
 	// is what neighbours in those directions need.
 	const bool can_fuse = h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
 	bool extrapolating = true;     // every face of type 0 or 1
 	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
-	h->gen = can_fuse && extrapolating && ((!dirichlet && var) || (h->cart && (var || dirichlet)));
+	h->gen = can_fuse && extrapolating && (!dirichlet || h->cart);
+	h->inbc = h->gen && !var && !dirichlet;
 	h->fused = can_fuse && ((dirichlet && !h->cart) || h->gen);
 	choose_chunk_depth(h);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
@@ -1860,6 +1862,10 @@ static int solve_tail(kry_handle h, double *phi, int debug)
 		printf(" Norm: %g %g %g %g %d\n", h->norm_final, h->norm_final / h->norm_rhs, h->norm_rhs,
 		       h->d.eps * h->norm_rhs, h->it_base);
 	}
+	// After its loop the reference recomputes the true residual (solveLin_BICGStab.C:512-518); the
+	// value is unused, but the constant-coefficient operator passes its input -- phi -- through
+	// do_BCs (Krylov.C:516): the caller's phi comes back with its boundary cells re-extrapolated.
+	if (!h->var && h->it_base > 0 && (st == KRY_OK || st == KRY_MAX_ITER)) CHK(g_do_bcs(h, &Slab::phi));
 	int st2 = finish_solve(h, phi);
 	return st2 < 0 ? st2 : st;
 }
@@ -1959,6 +1965,7 @@ static int op_prepare(kry_handle h, bool var, bool offd, const double Dc[3])
 	h->loaded = false;
 	drop_graph(h);
 	h->gen = false;
+	h->inbc = false;
 	h->var = var;
 	h->offd = var && offd;
 	make_op(h, var, Dc);

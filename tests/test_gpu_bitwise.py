@@ -154,6 +154,45 @@ def test_general_boundary_fused_path_matches_oracle_in_device_order(orc, bc, L):
 
 
 @pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("bc", MIXED + [(1, 1, 1, 0, 0, 1), (0, 1, 1, 1, 1, 0)])
+def test_constant_coefficients_on_general_faces_fused_path(orc, bc, L):
+    """The constant-coefficient operator passes its INPUT through do_BCs (Krylov.C:516), which
+    rewrites boundary planes and ghost cells of the iteration vectors before every application.
+    The fused general-boundary kernels evaluate that treatment cell by cell while they form the
+    input; against the oracle, which applies do_BCs as the reference does."""
+    p = P.reference_test1(24)
+    p.bc = bc
+    p.rhs = np.random.default_rng(13).uniform(-1, 1, p.rhs.shape)
+    p.phi = 1e-2 * np.random.default_rng(14).uniform(-1, 1, p.phi.shape)     # a start vector that do_BCs changes
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=40)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=40)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9), (16, 62, 16), (128, 8, 8)])
+def test_constant_coefficients_on_general_faces_ragged_shapes(orc, n, L):
+    """mx a multiple of the tile width (the upper x face then lies in the halo column), several
+    tiles per row, tile edges inside the ghost layer, chunks of a few planes."""
+    q = P.smooth_var(n, bc=(1, 1, 1, 1, 1, 1))
+    p = P.Problem("const", q.mx, q.delx, q.bc, False, False, (1., 2., 3.), q.phi, q.rhs, q.lam)
+    p.rhs = np.random.default_rng(15).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=25)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=25)
+
+
+@pytest.mark.parametrize("nslabs", [2, 4])
+def test_constant_coefficients_on_general_faces_slabs(orc, nslabs):
+    p = P.reference_test1((24, 20, 32))
+    p.bc = (1, 0, 1, 1, 1, 1)
+    p.rhs = np.random.default_rng(16).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, 2, eps=1e-13, max_outer=25, nslabs=nslabs)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=10)
+
+
+@pytest.mark.parametrize("L", [1, 2])
 @pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9), (16, 62, 16)])
 def test_general_boundary_fused_path_ragged_shapes(orc, n, L):
     """Tile edges that fall inside the ghost layer, several tiles per row, short chunks."""

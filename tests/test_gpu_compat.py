@@ -75,8 +75,8 @@ def test_three_field_overload(orc):
 
 
 def test_adaptor_mixed_faces():
-    """Field coefficients with extrapolating faces: the fused general-boundary
-    kernels; constant coefficients: one kernel per primitive."""
+    """Extrapolating faces run the fused general-boundary kernels, with field
+    coefficients and with constant ones."""
     p = P.smooth_var(16, bc=(0, 0, 1, 1, 0, 1))
     a = adaptor_solve(p, 2, 1e-6)
     b = capi.solve_problem(p, L=2, eps=1e-6)
@@ -86,7 +86,7 @@ def test_adaptor_mixed_faces():
     q.bc = (0, 0, 1, 1, 0, 1)
     a = adaptor_solve(q, 2, 1e-6)
     b = capi.solve_problem(q, L=2, eps=1e-6)
-    assert not a["fused"] and b["path"] == 0
+    assert a["fused"] and b["path"] == 2
     assert np.array_equal(a["history"], b["history"])
 
 
