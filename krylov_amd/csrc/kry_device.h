@@ -99,5 +99,10 @@ enum KryPhase {
 	PH_BL1,       // l=1 last B: sums = (r0,r1), (r1,r1)          -> omega
 	PH_BL2,       // l=2 last B: sums = (r1,r1), (r2,r1)          -> sigma1, tau12
 	PH_M2,        // l=2 MR:     sums = (r2,r2), (r0,r2), (r0,r1) -> gammap1, gammas, omega
-	PH_F          // sums = |r0|^2, (r0, r~)                      -> norm, convergence, next rho/beta
+	PH_F,         // sums = |r0|^2, (r0, r~)                      -> norm, convergence, next rho/beta
+	// general l (the index jj, and ii for PH_TAU, ride in the phase word: see KRY_PHASE)
+	PH_BN,        // last B kernel of the BiCG part: only the alpha check, its dot is not used
+	PH_TAU,       // sums[0] = (r_jj, r_ii)                       -> tau[ii][jj]
+	PH_SIG        // sums = (r_jj, r_jj), (r0, r_jj)              -> sigma[jj], gammap[jj]; jj = l: omega, gamma, gamma''
 };
+#define KRY_PHASE(ph, jj, ii) ((ph) | ((jj) << 8) | ((ii) << 16))

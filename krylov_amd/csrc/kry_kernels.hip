@@ -35,9 +35,10 @@ __device__ inline bool really_is_nan(double xd)
 	return (__float_as_uint(x) & 0x7F800000u) == 0x7F800000u;
 }
 
-__device__ void kry_scalar_step(KryState *S, int phase)
+__device__ void kry_scalar_step(KryState *S, int phase_word)
 {
 	const double *s = S->sums;
+	const int phase = phase_word & 0xff, jj = (phase_word >> 8) & 0xff, ii = (phase_word >> 16) & 0xff;
 	switch (phase) {
 	case PH_INIT: {
 		double n = sqrt(s[0]);
@@ -108,6 +109,28 @@ __device__ void kry_scalar_step(KryState *S, int phase)
 		S->rho1 = rho1;
 		break;
 	}
+	case PH_BN:
+		if (really_is_nan(S->alpha)) { S->status = 1; S->done = 1; }          // :406-409
+		break;
+	case PH_TAU:
+		S->tau[ii][jj] = s[0] / S->sigma[ii];                                 // :422
+		break;
+	case PH_SIG: {
+		const int L = S->L;
+		S->sigma[jj] = s[0];                                                  // :427
+		S->gammap[jj] = s[1] / S->sigma[jj];                                  // :428
+		if (jj < L) break;
+		S->omega = S->gamma[L] = S->gammap[L];                                // :431
+		for (int j = L - 1; j >= 1; --j) {                                    // :434-439
+			S->gamma[j] = S->gammap[j];
+			for (int i = j + 1; i <= L; ++i) S->gamma[j] -= S->tau[j][i] * S->gamma[i];
+		}
+		for (int j = 1; j < L; ++j) {                                         // :441-446
+			S->gammapp[j] = S->gamma[j + 1];
+			for (int i = j + 1; i < L; ++i) S->gammapp[j] += S->tau[j][i] * S->gamma[i + 1];
+		}
+		break;
+	}
 	default: break;
 	}
 }
@@ -115,7 +138,7 @@ __device__ void kry_scalar_step(KryState *S, int phase)
 __global__ void k_scalar(KryState *S, int phase)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		if (S->done && phase != PH_INIT) return;
+		if (S->done && (phase & 0xff) != PH_INIT) return;
 		kry_scalar_step(S, phase);
 	}
 }
@@ -1092,6 +1115,197 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 }
 
 // ---------------------------------------------------------------------------
+// general l (l > 2): streaming kernels with the shape of k_mgs2 / k_final (2048-double plane
+// segments x plane groups, per-thread sums in the same order), scalars from the device state
+// ---------------------------------------------------------------------------
+
+// Pointwise statements of a BiCG step that no stencil kernel carries
+// (solveLin_BICGStab.C:356-362 and 392-394 for ii < jj, :403): dst = x + y*c per listed triple.
+__global__ __launch_bounds__(NT) void k_axpyn(const KryStream a, const KryOps ops)
+{
+	const KryState *S = a.S;
+	if (S->done) return;
+	constexpr int UN = SEG2 / NT;
+	const double nbeta = -S->beta, nalpha = -S->alpha, alpha = S->alpha;
+	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+		const long pb = (long)(a.zfirst + pl + 1) * a.g.ps + QOFF;
+		for (int o = 0; o < ops.n; ++o) {
+			const double c = ops.op[o].coef == KC_NBETA ? nbeta : (ops.op[o].coef == KC_NALPHA ? nalpha : alpha);
+			double2 x[UN], y[UN];
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long p = pb + q0 + 2L * i * NT;
+				x[i] = ld2s(ops.op[o].x + p);
+				y[i] = ld2s(ops.op[o].y + p);
+			}
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long q = q0 + 2L * i * NT;
+				if (q < a.g.ps) st2s(ops.op[o].dst + pb + q, axpy2(x[i], y[i], c));
+			}
+		}
+	}
+}
+
+// One step of the modified Gram-Schmidt part (solveLin_BICGStab.C:419-428) for r_jj:
+// first the update the previous step's dot product made possible, r_jj -= tau[iip][jj]*r_iip
+// (iip = 0: none pending), then either the next dot (r_jj, r_ii), or -- last step of this jj --
+// sigma_jj = (r_jj, r_jj) and (r_0, r_jj).
+template <bool GEN>
+__global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip, int last)
+{
+	KryState *S = a.S;
+	if (S->done) return;
+	constexpr int UN = SEG2 / NT;
+	const double ntau = iip > 0 ? -S->tau[iip][jj] : 0.;
+	double acc[2] = {0., 0.};
+	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	double wxy[GEN ? UN : 1][2];
+	if (GEN) {
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			bool c[2];
+			plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], c);
+		}
+	}
+	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+		const int z = a.zfirst + pl;
+		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
+		const long pb = (long)(z + 1) * a.g.ps + QOFF;
+		double2 rj[UN], rp[UN], rk[UN];
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			const long p = pb + q0 + 2L * i * NT;
+			rj[i] = ld2s(a.v[0] + p);
+			if (iip > 0) rp[i] = ld2s(a.v[1] + p);
+			rk[i] = ld2s(a.v[2] + p);
+		}
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			const long q = q0 + 2L * i * NT;
+			if (q < a.g.ps) {
+				if (iip > 0) {
+					rj[i] = axpy2(rj[i], rp[i], ntau);
+					st2s(a.w[0] + pb + q, rj[i]);
+				}
+				if (cnt) {
+					double w0 = 1., w1 = 1.;
+					if (GEN) {
+						const bool bz = (z == 0 && !a.g.has_lo) || (z == a.g.mz && !a.g.has_hi);
+						const double wz = bz ? 0.5 : 1.;
+						w0 = wxy[GEN ? i : 0][0] * wz;
+						w1 = wxy[GEN ? i : 0][1] * wz;
+					}
+					if (last) {
+						if (GEN) {
+							acc[0] += w0 * (rj[i].x * rj[i].x); acc[0] += w1 * (rj[i].y * rj[i].y);
+							acc[1] += w0 * (rk[i].x * rj[i].x); acc[1] += w1 * (rk[i].y * rj[i].y);
+						} else {
+							acc[0] += rj[i].x * rj[i].x; acc[0] += rj[i].y * rj[i].y;
+							acc[1] += rk[i].x * rj[i].x; acc[1] += rk[i].y * rj[i].y;
+						}
+					} else if (GEN) {
+						acc[0] += w0 * (rj[i].x * rk[i].x); acc[0] += w1 * (rj[i].y * rk[i].y);
+					} else {
+						acc[0] += rj[i].x * rk[i].x; acc[0] += rj[i].y * rk[i].y;
+					}
+				}
+			}
+		}
+	}
+	reduce_and_finalize<2>(acc, a.red);
+}
+
+// End of an outer pass for any l (solveLin_BICGStab.C:450-464), statement by statement:
+//   phi += gamma_1*r_0; r_0 -= gammap_L*r_L; u_0 -= gamma_L*u_L;
+//   for jj = 1..L-1: u_0 -= gamma_jj*u_jj; phi += gammapp_jj*r_jj; r_0 -= gammap_jj*r_jj;
+//   |r_0|^2 (norm weights) and (r_0, r~).
+template <bool GEN>
+__global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinalN f)
+{
+	KryState *S = a.S;
+	if (S->done) return;
+	constexpr int UN = SEG2 / NT;
+	const int L = f.L;
+	double acc[2] = {0., 0.};
+	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	double wxy[GEN ? UN : 1][2];
+	bool wcorner[GEN ? UN : 1][2];
+	if (GEN) {
+#pragma unroll
+		for (int i = 0; i < UN; ++i) plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], wcorner[GEN ? i : 0]);
+	}
+	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+		const int z = a.zfirst + pl;
+		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
+		const long pb = (long)(z + 1) * a.g.ps + QOFF;
+		double2 ph[UN], r0[UN], u0[UN], rt[UN];
+		{
+			const double g1 = S->gamma[1], gpL = S->gammap[L], gL = S->gamma[L];
+			double2 rl[UN], ul[UN];
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long p = pb + q0 + 2L * i * NT;
+				ph[i] = ld2s(a.w[0] + p);
+				r0[i] = ld2s(f.r[0] + p);
+				u0[i] = ld2s(f.u[0] + p);
+				rt[i] = ld2s(a.v[0] + p);
+				rl[i] = ld2s(f.r[L] + p);
+				ul[i] = ld2s(f.u[L] + p);
+			}
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				ph[i] = axpy2(ph[i], r0[i], g1);
+				r0[i] = axpy2(r0[i], rl[i], -gpL);
+				u0[i] = axpy2(u0[i], ul[i], -gL);
+			}
+		}
+		for (int j = 1; j < L; ++j) {
+			const double gj = S->gamma[j], gpj = S->gammap[j], gppj = S->gammapp[j];
+			double2 rj[UN], uj[UN];
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long p = pb + q0 + 2L * i * NT;
+				rj[i] = ld2s(f.r[j] + p);
+				uj[i] = ld2s(f.u[j] + p);
+			}
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				u0[i] = axpy2(u0[i], uj[i], -gj);
+				ph[i] = axpy2(ph[i], rj[i], gppj);
+				r0[i] = axpy2(r0[i], rj[i], -gpj);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < UN; ++i) {
+			const long q = q0 + 2L * i * NT;
+			if (q < a.g.ps) {
+				const long p = pb + q;
+				st2s(a.w[0] + p, ph[i]);
+				st2s(f.r0 + p, r0[i]);
+				st2s(f.u0 + p, u0[i]);
+				if (GEN) {
+					if (cnt) {
+						const bool bz = (z == 0 && !a.g.has_lo) || (z == a.g.mz && !a.g.has_hi);
+						const double wz = bz ? 0.5 : 1.;
+						const double w0 = wxy[GEN ? i : 0][0] * wz, w1 = wxy[GEN ? i : 0][1] * wz;
+						const double n0 = (bz && wcorner[GEN ? i : 0][0]) ? 0.25 : w0;
+						const double n1 = (bz && wcorner[GEN ? i : 0][1]) ? 0.25 : w1;
+						acc[0] += n0 * (r0[i].x * r0[i].x);   acc[0] += n1 * (r0[i].y * r0[i].y);
+						acc[1] += w0 * (r0[i].x * rt[i].x); acc[1] += w1 * (r0[i].y * rt[i].y);
+					}
+				} else if (cnt) {
+					acc[0] += r0[i].x * r0[i].x;   acc[0] += r0[i].y * r0[i].y;
+					acc[1] += r0[i].x * rt[i].x; acc[1] += r0[i].y * rt[i].y;
+				}
+			}
+		}
+	}
+	reduce_and_finalize<2>(acc, a.red);
+}
+
+// ---------------------------------------------------------------------------
 // generic kernels: one per primitive, any face type
 // ---------------------------------------------------------------------------
 
@@ -1453,6 +1667,26 @@ hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStre
 	else if (L == 1) hipLaunchKernelGGL((k_final<1, true>), dim3(nbx, nby), dim3(NT), 0, st, a);
 	else if (L == 2) hipLaunchKernelGGL((k_final<2, true>), dim3(nbx, nby), dim3(NT), 0, st, a);
 	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_axpyn(const KryStream &a, const KryOps &ops, int nbx, int nby, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_axpyn, dim3(nbx, nby), dim3(NT), 0, st, a, ops);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_mgsn(const KryStream &a, int jj, int iip, int last, int nbx, int nby, hipStream_t st)
+{
+	if (a.gen) hipLaunchKernelGGL(k_mgsn<true>, dim3(nbx, nby), dim3(NT), 0, st, a, jj, iip, last);
+	else hipLaunchKernelGGL(k_mgsn<false>, dim3(nbx, nby), dim3(NT), 0, st, a, jj, iip, last);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_finaln(const KryStream &a, const KryFinalN &f, int nbx, int nby, hipStream_t st)
+{
+	if (a.gen) hipLaunchKernelGGL(k_finaln<true>, dim3(nbx, nby), dim3(NT), 0, st, a, f);
+	else hipLaunchKernelGGL(k_finaln<false>, dim3(nbx, nby), dim3(NT), 0, st, a, f);
 	return hipGetLastError();
 }
 

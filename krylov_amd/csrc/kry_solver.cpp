@@ -683,9 +683,121 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 	return 0;
 }
 
+// One outer pass for l > 2, solveLin_BICGStab.C:341-464 statement by statement.  Per BiCG
+// step jj: an A kernel (u_jj = r_jj - beta*u_jj ; u_jj+1 = A u_jj ; (u_jj+1, r~)), one
+// pointwise sweep for the statements on the vectors below jj and phi, a B kernel
+// (r_jj -= alpha*u_jj+1 ; r_jj+1 = A r_jj ; (r_jj+1, r~)).  Then the modified Gram-Schmidt
+// part, one streaming kernel per dot product (the update a dot makes possible rides in the
+// next kernel), and the end-of-pass kernel.
+// Buffers: r_0 and u_0 alternate between their two copies with the pass; r_k and u_k,
+// 0 < k < l, are produced by a stencil kernel into copy 1 and move to copy 0 with the
+// update of step jj = k, where the later pointwise statements keep them; r_l, u_l: copy 0.
+int fused_pass_general(kry_solver *h, int it)
+{
+	const int p = it & 1;
+	const int L = h->L;
+	int cr[KRY_LMAX + 1], cu[KRY_LMAX + 1];
+	for (int k = 0; k <= L; ++k) cr[k] = cu[k] = (k == 0) ? p : (k < L ? 1 : 0);
+	auto flip = [&](int *c, int k) { c[k] = (k == 0) ? 1 - p : 0; };
+	auto for_slabs = [&](auto &&fn) -> int {
+		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
+		return 0;
+	};
+
+	for (int jj = 0; jj < L; ++jj) {
+		{
+			const int from = cu[jj];
+			flip(cu, jj);
+			CHK(stencil_step(h, KF_A1, [&](Slab &s) {
+				KryFused a = fused_base(h, s, PH_A);
+				a.X = s.rb[jj][cr[jj]].p; a.Y = s.ub[jj][from].p; a.Xout = s.ub[jj][cu[jj]].p;
+				a.O = s.ub[jj + 1][cu[jj + 1]].p;
+				return a;
+			}));
+			CHK(reduce_sums(h, PH_A));
+		}
+		// :356-362 and :392-394 for ii < jj, :403
+		CHK(for_slabs([&](Slab &s, int) -> int {
+			int nbx, nby;
+			KryStream a = stream_base(h, s, PH_NONE, &nbx, &nby, 1);
+			KryOps ops;
+			ops.n = 0;
+			auto add = [&](double *dst, const double *x, const double *y, int coef) {
+				ops.op[ops.n].dst = dst; ops.op[ops.n].x = x; ops.op[ops.n].y = y; ops.op[ops.n].coef = coef;
+				++ops.n;
+			};
+			for (int ii = 0; ii < jj; ++ii) add(s.ub[ii][cu[ii]].p, s.rb[ii][cr[ii]].p, s.ub[ii][cu[ii]].p, KC_NBETA);
+			for (int ii = 0; ii < jj; ++ii) add(s.rb[ii][cr[ii]].p, s.rb[ii][cr[ii]].p, s.ub[ii + 1][cu[ii + 1]].p, KC_NALPHA);
+			add(s.phi.p, s.phi.p, s.ub[0][cu[0]].p, KC_ALPHA);
+			HIPCHK(hipSetDevice(s.device));
+			prof_begin(h, s, 6);
+			HIPCHK(kry_launch_axpyn(a, ops, nbx, nby, s.st));
+			prof_end(h, s);
+			return 0;
+		}));
+		{
+			const int from = cr[jj];
+			flip(cr, jj);
+			const int phase = (jj < L - 1) ? PH_B : PH_BN;
+			CHK(stencil_step(h, KF_B0, [&](Slab &s) {
+				KryFused a = fused_base(h, s, phase);
+				a.X = s.rb[jj][from].p; a.Y = s.ub[jj + 1][cu[jj + 1]].p; a.Xout = s.rb[jj][cr[jj]].p;
+				a.O = s.rb[jj + 1][cr[jj + 1]].p;
+				return a;
+			}));
+			CHK(reduce_sums(h, phase));
+		}
+	}
+
+	// MR part, :419-446
+	for (int jj = 1; jj <= L; ++jj) {
+		for (int step = 1; step <= jj; ++step) {
+			// step < jj: the dot (r_jj, r_step) after the update with r_step-1; step = jj: sigma_jj, (r_0, r_jj)
+			const int last = (step == jj), iip = step - 1;
+			const int phase = last ? KRY_PHASE(PH_SIG, jj, 0) : KRY_PHASE(PH_TAU, jj, step);
+			CHK(for_slabs([&](Slab &s, int) -> int {
+				int nbx, nby;
+				KryStream a = stream_base(h, s, phase, &nbx, &nby, 4);
+				a.v[0] = s.rb[jj][cr[jj]].p;
+				a.v[1] = iip > 0 ? s.rb[iip][cr[iip]].p : nullptr;
+				a.v[2] = last ? s.rb[0][cr[0]].p : s.rb[step][cr[step]].p;
+				a.w[0] = s.rb[jj][cr[jj]].p;
+				HIPCHK(hipSetDevice(s.device));
+				prof_begin(h, s, 6);
+				HIPCHK(kry_launch_mgsn(a, jj, iip, last, nbx, nby, s.st));
+				prof_end(h, s);
+				return 0;
+			}));
+			CHK(reduce_sums(h, phase));
+		}
+	}
+
+	// :450-464
+	CHK(for_slabs([&](Slab &s, int) -> int {
+		int nbx, nby;
+		KryStream a = stream_base(h, s, PH_F, &nbx, &nby, 1);
+		KryFinalN f;
+		memset(&f, 0, sizeof f);
+		f.L = L;
+		for (int k = 0; k <= L; ++k) { f.r[k] = s.rb[k][cr[k]].p; f.u[k] = s.ub[k][cu[k]].p; }
+		f.r0 = s.rb[0][cr[0]].p;
+		f.u0 = s.ub[0][cu[0]].p;
+		a.v[0] = s.rt.p;
+		a.w[0] = s.phi.p;
+		HIPCHK(hipSetDevice(s.device));
+		prof_begin(h, s, 7);
+		HIPCHK(kry_launch_finaln(a, f, nbx, nby, s.st));
+		prof_end(h, s);
+		return 0;
+	}));
+	CHK(reduce_sums(h, PH_F));
+	return 0;
+}
+
 // one outer pass, solveLin_BICGStab.C:327-496, as fused kernels
 int fused_pass(kry_solver *h, int it)
 {
+	if (h->L > 2) return fused_pass_general(h, it);
 	const int p = it & 1, q = 1 - p;
 	const int L = h->L;
 	auto for_slabs = [&](auto &&fn) -> int {
@@ -1323,7 +1435,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	// that variant evaluates cell by cell while it forms the input (`inbc`).
 	// A split in x or y runs the general-boundary variant too: its ghost-cell handling
 	// is what neighbours in those directions need.
-	const bool can_fuse = h->L <= 2 && !(h->d.flags & KRY_FORCE_GENERIC);
+	const bool can_fuse = !(h->d.flags & KRY_FORCE_GENERIC);
 	bool extrapolating = true;     // every face of type 0 or 1
 	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
 	h->gen = can_fuse && extrapolating && (!dirichlet || h->cart);
@@ -1493,7 +1605,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 				// vectors that feed a fused stencil after an update need a ping-pong partner;
 				// so does u1, which the first stencil kernel of a pass both reads (deferred
 				// u0 update) and produces
-				const int nb = ((k < h->L || k == 1) && h->L <= 2) ? 2 : 1;
+				const int nb = (k < h->L || k == 1) ? 2 : 1;
 				for (int b = 0; b < nb; ++b) {
 					CHK(alloc_field(s, s.rb[k][b]));
 					CHK(alloc_field(s, s.ub[k][b]));
@@ -1907,7 +2019,11 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	int W;
 	if (h->L == 1) W = h->var ? (h->offd ? 28 : 26) : 20;
 	else if (h->L == 2) W = h->var ? (h->offd ? 66 : 62) : 50;
-	else W = 0;
+	else {
+		// 2l stencil kernels, the pointwise sweeps (3 l^2), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
+		const int per_stencil = h->var ? (h->offd ? 10 : 9) : 6;
+		W = 2 * h->L * per_stencil + 5 * h->L * h->L + 2 * h->L + 7;
+	}
 	const double npts = ((double)h->d.mx[0] * h->np[0] + 1) * ((double)h->d.mx[1] * h->np[1] + 1) *
 	                    ((double)h->mzl * h->d.nslabs + 1);
 	o->bytes_per_iter = 8.0 * W * npts;

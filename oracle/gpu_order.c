@@ -409,6 +409,8 @@ static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int n
 static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b)
 {
 	(void)ctx;
+	/* l > 2: every dot of the Gram-Schmidt part has a streaming kernel of its own (k_mgsn) */
+	const int big = c->L > 2;
 	if (g_mode == 2) {   /* generic path: every reduction is a g_wdot launch */
 		if (site == ORC_SITE_NORM_RHS || site == ORC_SITE_NORM_INIT || site == ORC_SITE_NORM)
 			return sqrt(wdot_sum(c, a, b, 1));
@@ -421,9 +423,9 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 		case ORC_SITE_RHO:
 			if (jj == 0) return iter == 1 ? wdot_sum(c, a, b, 0) : stream_gen_sum(c, a, b, 1, 0);
 			return fused_gen_sum(c, a, b);
-		case ORC_SITE_ALPHA:
-		case ORC_SITE_TAU:       return fused_gen_sum(c, a, b);
-		case ORC_SITE_SIGMA:     return jj == 1 ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
+		case ORC_SITE_ALPHA:     return fused_gen_sum(c, a, b);
+		case ORC_SITE_TAU:       return big ? stream_gen_sum(c, a, b, 4, 0) : fused_gen_sum(c, a, b);
+		case ORC_SITE_SIGMA:     return (jj == 1 && !big) ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
 		case ORC_SITE_GAMMAP:    /* l = 2: the dot (r0, r1) rides in k_mgs2 */
 			return (jj == 1 && c->L == 1) ? fused_gen_sum(c, a, b) : stream_gen_sum(c, a, b, 4, 0);
 		case ORC_SITE_NORM:      return sqrt(stream_gen_sum(c, a, b, 1, 1));
@@ -438,8 +440,8 @@ static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, cons
 		                              : stream_sum(c, a, b, 1);           /* end-of-pass kernel */
 		return fused_sum(c, a, b);                                        /* B kernel of jj-1 */
 	case ORC_SITE_ALPHA:     return fused_sum(c, a, b);                   /* A kernels */
-	case ORC_SITE_TAU:       return fused_sum(c, a, b);                   /* last B kernel */
-	case ORC_SITE_SIGMA:     return jj == 1 ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);   /* k_mgs2 */
+	case ORC_SITE_TAU:       return big ? stream_sum(c, a, b, 4) : fused_sum(c, a, b);   /* k_mgsn : last B kernel */
+	case ORC_SITE_SIGMA:     return (jj == 1 && !big) ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);   /* k_mgs2, k_mgsn */
 	case ORC_SITE_GAMMAP:    /* l = 2: the dot (r0, r1) rides in k_mgs2 */
 		return (jj == 1 && c->L == 1) ? fused_sum(c, a, b) : stream_sum(c, a, b, 4);
 	case ORC_SITE_NORM:      return sqrt(stream_sum(c, a, b, 1));

@@ -229,6 +229,79 @@ def test_high_contrast_mixed_faces_workload(orc, L):
     assert_identical(want, got, min_passes=40)
 
 
+# ---- l > 2: one stencil kernel pair per BiCG step, one streaming kernel per Gram-Schmidt dot ----
+
+@pytest.mark.parametrize("L", [3, 4, 6])
+@pytest.mark.parametrize("kind,n", [("const_random_rhs", 32), ("var_random_rhs", 48), ("offdiag", 32), ("ref_test2", 32)])
+def test_fused_path_any_l(orc, kind, n, L):
+    p = make(kind, n)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=24)
+    assert got["path"] == 1
+    assert_identical(want, got, min_passes=3)
+
+
+def test_fused_path_largest_l(orc):
+    p = make("var_random_rhs", 32)
+    want, got = run_pair(orc, p, 8, eps=1e-13, max_outer=6)
+    assert got["path"] == 1
+    assert_identical(want, got, min_passes=3)
+
+
+@pytest.mark.parametrize("L", [3, 4])
+def test_fused_path_any_l_to_convergence(orc, L):
+    p = make("var_random_rhs", 32)
+    want, got = run_pair(orc, p, L, eps=1e-6, max_outer=0)
+    assert got["status"] == 0
+    assert_identical(want, got, min_passes=5)
+
+
+@pytest.mark.parametrize("L", [3, 4])
+@pytest.mark.parametrize("bc", [(0, 0, 1, 1, 0, 1), (1, 1, 1, 1, 1, 1), (0, 1, 0, 0, 0, 0)])
+def test_general_boundary_fused_path_any_l(orc, bc, L):
+    p = P.smooth_var(24, bc=bc)
+    p.rhs = np.random.default_rng(3).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=3)
+
+
+@pytest.mark.parametrize("L", [3, 5])
+@pytest.mark.parametrize("bc", [(1, 0, 0, 1, 1, 0), (1, 1, 1, 0, 0, 1)])
+def test_constant_coefficients_on_general_faces_any_l(orc, bc, L):
+    p = P.reference_test1((40, 20, 28))
+    p.bc = bc
+    p.rhs = np.random.default_rng(13).uniform(-1, 1, p.rhs.shape)
+    p.phi = 1e-2 * np.random.default_rng(14).uniform(-1, 1, p.phi.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=15)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=3)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("nslabs", [2, 4])
+@pytest.mark.parametrize("kind,n,L", [("const_random_rhs", 32, 3), ("var_random_rhs", (40, 24, 64), 4)])
+def test_slab_runs_any_l(orc, monkeypatch, kind, n, L, nslabs, overlap):
+    monkeypatch.setenv("KRY_OVERLAP", overlap)
+    monkeypatch.setenv("KRY_ZC", "4")
+    if isinstance(n, tuple):
+        p = P.smooth_var(n)
+        p.rhs = np.random.default_rng(17).uniform(-1, 1, p.rhs.shape)
+    else:
+        p = make(kind, n)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=15, nslabs=nslabs, split=(overlap == "1"))
+    assert got["path"] == 1
+    assert_identical(want, got, min_passes=3)
+
+
+@pytest.mark.parametrize("nslabs", [2, 4])
+def test_general_boundary_slab_runs_any_l(orc, nslabs):
+    p = P.smooth_var((24, 20, 32), bc=(1, 1, 0, 1, 1, 1))
+    p.rhs = np.random.default_rng(3).uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, 3, eps=1e-13, max_outer=15, nslabs=nslabs)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=3)
+
+
 def test_summation_order_alone_moves_the_history(orc):
     """Reference order against device order, both on the CPU oracle: identical
     arithmetic, different summation order.  The histories agree at the start and

@@ -73,11 +73,12 @@ def test_full_solve_on_slabs(orc, nslabs):
 
 @pytest.mark.parametrize("nslabs", [2, 4])
 @pytest.mark.parametrize("L,flags,path", [(1, 0, 2), (2, 0, 2), (1, capi.KRY_FORCE_GENERIC, 0),
-                                          (2, capi.KRY_FORCE_GENERIC, 0), (3, 0, 0)])
+                                          (2, capi.KRY_FORCE_GENERIC, 0), (3, 0, 2),
+                                          (3, capi.KRY_FORCE_GENERIC, 0)])
 @pytest.mark.parametrize("bc", [(0, 0, 1, 1, 0, 1), (1, 1, 0, 1, 1, 1)])
 def test_mixed_faces_on_slabs(orc, bc, nslabs, L, flags, path):
-    """Extrapolating faces across slabs: the fused general-boundary kernels (l <= 2)
-    and the one-kernel-per-primitive path."""
+    """Extrapolating faces across slabs: the fused general-boundary kernels and the
+    one-kernel-per-primitive path."""
     p = P.smooth_var(24, bc=bc)
     p.rhs = np.random.default_rng(9).uniform(-1, 1, p.rhs.shape)
     want = oracle_solve(orc, p, L=L, eps=1e-30, max_outer=3)

@@ -94,7 +94,7 @@ def test_smooth_var_fused_vs_generic(orc, L):
 @pytest.mark.parametrize("L", [1, 2, 4])
 def test_mixed_boundaries(orc, L):
     p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1))
-    compare(orc, p, L, expect_fused=(L <= 2))          # general-boundary fused kernels for l <= 2
+    compare(orc, p, L, expect_fused=True)              # general-boundary fused kernels, any l
     compare(orc, p, L, flags=capi.KRY_FORCE_GENERIC, expect_fused=False)
 
 
