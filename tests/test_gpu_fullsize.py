@@ -1,11 +1,12 @@
 """Full-size checks at 256^3, 512^3 and on the 1024 x 1024 x 128 block (the sizes of
-the benchmark configs), where the CPU oracle would take minutes to hours:
-size-independent properties and cross-checks between the library's two device
-implementations only."""
+the benchmark configs).  A converged solve of the CPU oracle would take minutes to
+hours there: the first passes are compared with the oracle bit for bit, the rest
+are size-independent properties and cross-checks between the library's two device
+implementations."""
 import numpy as np
 import pytest
 
-from helpers import points, rel_l2
+from helpers import oracle_solve, points, rel_l2
 from krylov_amd import capi, problems as P
 
 pytestmark = pytest.mark.gpu
@@ -123,3 +124,32 @@ def test_eight_gpu_slab_shape_split_launch(monkeypatch, overlap):
     # (summation order differs between the two layouts; by the fourth pass that is a few 1e-10)
     assert np.max(np.abs(hist[0] - hist[1]) / hist[0]) <= 1e-9
     assert abs(hist[0][0] - hist[1][0]) / hist[0][0] <= 1e-12
+
+
+def _bench_problem(n, workload):
+    import bench
+    f = bench.slab_problem(n, 1, 0, workload)
+    if workload == "const":
+        return P.Problem("const", f["mx"], f["delx"], f["bc"], False, False, tuple(f["Dc"]), f["phi"], f["rhs"], f["lam"])
+    return P.Problem(workload, f["mx"], f["delx"], f["bc"], True, False, (1., 1., 1.), f["phi"], f["rhs"], f["lam"],
+                     f["Dxx"], f["Dyy"], f["Dzz"], np.zeros_like(f["phi"]))
+
+
+@pytest.mark.parametrize("n,workload,L,passes", [(256, "const", 1, 4), (256, "const", 2, 2), (256, "mixed", 2, 2),
+                                                 (512, "var", 2, 3), (512, "var", 1, 2), (512, "mixed", 2, 2)])
+def test_benchmark_grids_first_passes_against_the_oracle_bit_for_bit(orc, n, workload, L, passes):
+    """The benchmark's own problems at their own sizes (256^3 constant coefficients, the 256^3
+    high-contrast mixed-face problem, 512^3 field coefficients): the first passes of the device
+    solve and of the oracle summing in the device's order carry the same bits."""
+    p = _bench_problem(n, workload)
+    got = capi.solve_problem(p, L=L, eps=0.0, max_outer=passes)
+    ty, zc, sb = got["order"]
+    orc.use_gpu_order({1: 1, 2: 3}[got["path"]], ty, zc, sb)
+    try:
+        want = oracle_solve(orc, p, L=L, eps=0.0, max_outer=passes)
+    finally:
+        orc.use_gpu_order(0)
+    assert got["iters"] == want["iters"] == passes
+    assert got["norm_rhs"] == want["norm_rhs"] and got["norm_init"] == want["norm_init"]
+    assert np.max(np.abs(got["history"] - want["history"]) / want["norm_rhs"]) <= 1e-15
+    assert np.array_equal(points(got["phi"]), points(want["phi"]))
