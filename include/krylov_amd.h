@@ -81,7 +81,7 @@ typedef struct kry_stats {
 	int    status;
 	int    iterations;       /* outer iterations executed by the last solve/iterate */
 	int    fused;            /* 1: fused kernels, all faces Dirichlet; 2: fused kernels, general
-	                            faces (field coefficients); 0: one kernel per primitive */
+	                            faces; 0: one kernel per primitive */
 	double norm_rhs;
 	double norm_init;
 	double norm_final;

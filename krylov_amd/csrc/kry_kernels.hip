@@ -1,12 +1,14 @@
 // gfx950 kernels of the BiCGStab(l) stencil solver.
 //
 // Two families:
-//   * fused Dirichlet kernels (k_fused, k_final, k_mgs2): LDS-tiled, z-marching
-//     stencil fused with the vector update that produces its input and with the
-//     dot products that consume its output; wave64 shuffles + a single-pass grid
-//     reduction whose last block also advances the scalar recurrences.
-//   * generic kernels (g_*): one kernel per primitive, any face type, used for
-//     Neumann / mixed boundaries, for l > 2 and as an independent cross-check.
+//   * fused kernels (k_fused, k_surf, k_mgs2, k_final; k_axpyn, k_mgsn, k_finaln for
+//     l > 2): LDS-tiled, z-marching stencil fused with the vector update that produces
+//     its input and with the dot products that consume its output; wave64 shuffles + a
+//     single-pass grid reduction whose last block also advances the scalar recurrences.
+//     Dirichlet faces, or (GEN instantiations) any mix of Dirichlet and extrapolating faces.
+//   * generic kernels (g_*): one kernel per primitive, any face type: the prologue of
+//     the general-face path, face types the fused kernels do not know, and an
+//     independent cross-check of every configuration.
 //
 // The translation unit is built with -ffp-contract=off: every product and sum
 // below rounds separately, in the order the reference evaluates them
