@@ -66,7 +66,8 @@ def run_ranks(world, kind, L, max_outer, eps, outdir, nproc=None):
 
 @gpu
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2), ("mixed", 1), ("mixed_generic", 2)])
+@pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2), ("mixed", 1), ("mixed_generic", 2),
+                                    ("var", 3), ("mixed", 4)])
 def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     from helpers import points, rel_l2
     from krylov_amd import capi
@@ -94,7 +95,7 @@ def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
 @gpu
 @pytest.mark.parametrize("nproc", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)])
 @pytest.mark.parametrize("kind,L", [("const", 2), ("var", 2), ("var", 1), ("offdiag", 2), ("mixed32", 2),
-                                    ("var_generic", 2), ("const_generic", 1)])
+                                    ("var_generic", 2), ("const_generic", 1), ("offdiag", 3)])
 def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, nproc):
     """Sub-domains in x and y as well (the reference's mpi_manager_3D layout, up to its
     driver's 2 x 2 x 2): three passes against the undivided solve."""
@@ -126,7 +127,8 @@ def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, 
 @pytest.mark.parametrize("world,kind,L,nproc", [(2, "var", 2, None), (4, "var", 2, None), (2, "const", 1, None),
                                                 (4, "mixed", 2, None), (2, "mixed_generic", 2, None),
                                                 (4, "var", 2, (1, 2, 2)), (4, "var", 1, (2, 2, 1)),
-                                                (8, "offdiag", 2, (2, 2, 2))])
+                                                (8, "offdiag", 2, (2, 2, 2)), (2, "var", 3, None),
+                                                (4, "mixed", 3, (1, 2, 2))])
 def test_mapped_memory_exchange_reproduces_the_transport(tmp_path, monkeypatch, world, kind, L, nproc):
     """The dot products all-reduced by the reduction kernels themselves through mailboxes, and the
     ghost planes pushed into landing slots, both in memory the processes map from each other (HIP
