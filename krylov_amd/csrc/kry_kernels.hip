@@ -701,6 +701,21 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			}
 		}
 		if (GEN && cstore) a.Xout[pb + coff] = col_psi();   // sx, sy, ... still hold plane z
+		if (GEN && DEFER && nz >= 1) {
+			// l = 1: the reference writes u1 = A u0 over the old u1 (one array), and the x-face treatment of that
+			// output reads the array's ghost rows j = -1, my+1 (BoundaryHandler.C:420-421), which still hold the
+			// old u1.  Here the output goes to the partner buffer: hand it the old ghost rows (the xy edge ghosts
+			// derived from them are read by the 11-point operator).
+#pragma unroll
+			for (int e = 0; e < VD; ++e) {
+				const int j = y0 + w * VD + e;
+				if (j == -1 || j == g.my + 1) {
+					if (uxx && uxy) st2(a.O + pb + off[e], nz1[DEFER ? e : 0]);
+					else if (uxx) a.O[pb + off[e]] = nz1[DEFER ? e : 0].x;
+					else if (uxy) a.O[pb + off[e] + 1] = nz1[DEFER ? e : 0].y;
+				}
+			}
+		}
 	};
 
 	// ---- prologue: planes z0-1, z0 and the loads of z0+1 ----
@@ -1094,6 +1109,13 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 				}
 				st2s(a.w[0] + p, phv);
 				st2s(a.w[1] + p, r0);
+				if (GEN && L == 2) {
+					// r2' = r2 - tau12*r1 lives in registers only, except on the ghost rows j = -1, my+1: the x-face
+					// treatment of the next r2 = A r1 reads them from this array (BoundaryHandler.C:420-421), and the
+					// reference's array holds r2' there (solveLin_BICGStab.C:424 acts on all cells)
+					const int row = (int)((q + QOFF) / a.g.px);
+					if (row == 0 || row == a.g.my + 2) st2(a.w[3] + p, r[i][2]);
+				}
 				if (GEN) {
 					if (cnt) {
 						// |r0|^2 with the norm's weights (corners 1/4, Krylov.C:136-143),

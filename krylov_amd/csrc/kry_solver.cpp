@@ -689,16 +689,18 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 // (r_jj -= alpha*u_jj+1 ; r_jj+1 = A r_jj ; (r_jj+1, r~)).  Then the modified Gram-Schmidt
 // part, one streaming kernel per dot product (the update a dot makes possible rides in the
 // next kernel), and the end-of-pass kernel.
-// Buffers: r_0 and u_0 alternate between their two copies with the pass; r_k and u_k,
-// 0 < k < l, are produced by a stencil kernel into copy 1 and move to copy 0 with the
-// update of step jj = k, where the later pointwise statements keep them; r_l, u_l: copy 0.
+// Buffers: every r_k and u_k, k < l, alternates between its two copies with the pass: the
+// stencil kernel that produces it (k > 0) writes over the latest version, copy p, as the
+// reference's one array is overwritten in place (the ghost rows it leaves alone feed the
+// x-face treatment of the output); the update of step jj = k moves it to copy q, where the
+// later pointwise statements keep it.  r_l, u_l: one copy.
 int fused_pass_general(kry_solver *h, int it)
 {
 	const int p = it & 1;
 	const int L = h->L;
 	int cr[KRY_LMAX + 1], cu[KRY_LMAX + 1];
-	for (int k = 0; k <= L; ++k) cr[k] = cu[k] = (k == 0) ? p : (k < L ? 1 : 0);
-	auto flip = [&](int *c, int k) { c[k] = (k == 0) ? 1 - p : 0; };
+	for (int k = 0; k <= L; ++k) cr[k] = cu[k] = (k < L) ? p : 0;
+	auto flip = [&](int *c, int k) { c[k] = 1 - p; };
 	auto for_slabs = [&](auto &&fn) -> int {
 		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
 		return 0;
@@ -807,13 +809,14 @@ int fused_pass(kry_solver *h, int it)
 
 	// u1 lives in ub[1][.]: l = 1 alternates the two buffers with the pass (the A kernel
 	// reads the old u1 from one and writes the new one to the other); l = 2 writes the
-	// operator output to [1] and the updated u1 (A kernel of jj = 1) back to [0]
+	// operator output over the latest u1 (copy p, as the reference's one array: its ghost rows
+	// feed the x-face treatment of the output) and the updated u1 (A kernel of jj = 1) to copy q
 	// --- jj = 0, A: u0 -= gamma_L*u_L [- gamma_1*u_1] (previous pass) ; u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
 	CHK(stencil_step(h, KF_A0, [&](Slab &s) {
 		KryFused a = fused_base(h, s, PH_A);
 		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
 		if (L == 1) { a.nz = 1; a.Z1 = s.ub[1][p].p; a.O = s.ub[1][q].p; }
-		else { a.nz = 0; a.O = s.ub[1][1].p; }
+		else { a.nz = 0; a.O = s.ub[1][p].p; }
 		return a;
 	}));
 	CHK(reduce_sums(h, PH_A));
@@ -831,7 +834,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 		CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_B);
-			a.X = s.rb[0][p].p; a.Y = s.ub[1][1].p; a.Xout = s.rb[0][q].p;
+			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][p].p;
 			return a;
 		}));
@@ -839,7 +842,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 1, A: u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
 		CHK(stencil_step(h, KF_A1, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_A);
-			a.X = s.rb[1][p].p; a.Y = s.ub[1][1].p; a.Xout = s.ub[1][0].p;
+			a.X = s.rb[1][p].p; a.Y = s.ub[1][p].p; a.Xout = s.ub[1][q].p;
 			a.O = s.ub[2][0].p;
 			return a;
 		}));
@@ -856,7 +859,7 @@ int fused_pass(kry_solver *h, int it)
 		CHK(for_slabs([&](Slab &s, int) -> int {
 			int nbx, nby;
 			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby, 4);
-			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p; a.v[3] = s.ub[1][0].p;
+			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p; a.v[3] = s.ub[1][q].p;
 			a.w[0] = s.rb[2][0].p;
 			HIPCHK(hipSetDevice(s.device));
 			prof_begin(h, s, 6);
@@ -879,9 +882,10 @@ int fused_pass(kry_solver *h, int it)
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p;
 			a.v[3] = s.ub[0][q].p;
 			a.v[4] = s.rt.p;
-			a.v[5] = s.ub[1][0].p;
+			a.v[5] = s.ub[1][q].p;
 			a.v[6] = s.ub[2][0].p;
 			a.w[2] = s.ub[0][q].p;
+			a.w[3] = s.rb[2][0].p;
 		}
 		a.w[0] = s.phi.p; a.w[1] = s.rb[0][q].p;
 		HIPCHK(hipSetDevice(s.device));

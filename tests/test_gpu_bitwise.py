@@ -204,7 +204,7 @@ def test_general_boundary_fused_path_ragged_shapes(orc, n, L):
     assert_identical(want, got, min_passes=30)
 
 
-@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
 def test_general_boundary_fused_path_with_offdiagonal_term(orc, L):
     """The 11-point operator reads edge ghosts, which only the whole-array update
     semantics and the face order of do_BCs define."""
@@ -214,6 +214,29 @@ def test_general_boundary_fused_path_with_offdiagonal_term(orc, L):
     want, got = run_pair(orc, p, L, eps=1e-13, max_outer=30)
     assert got["path"] == 2
     assert_identical(want, got, min_passes=30)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("bc", [(1, 1, 1, 1, 1, 1), (1, 0, 1, 1, 0, 1), (1, 1, 1, 0, 1, 1)])
+def test_edge_ghosts_with_offdiagonal_term_away_from_zero(orc, bc, L):
+    """Dxy that does not vanish on the faces: the operator value at an edge point then depends on
+    the xy edge ghost of its input, which the x-face treatment of an earlier operator output
+    derived from whatever the ghost rows of that array held at the time (do_BCs treats x first,
+    over the full tangential range, BoundaryHandler.C:420-421).  The device must keep every
+    array's ghost cells in step with the reference's arrays for this to come out equal."""
+    p = P.offdiag_var((24, 20, 28))
+    p.bc = bc
+    rng = np.random.default_rng(21)
+    p.Dxy = 0.05 + 0.1 * rng.uniform(0, 1, p.Dxy.shape)
+    p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20, flags=capi.KRY_FORCE_GENERIC)
+    assert_identical(want, got, min_passes=5)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=5)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20, nslabs=2)
+    assert got["path"] == 2
+    assert_identical(want, got, min_passes=5)
 
 
 @pytest.mark.parametrize("L", [1, 2])
