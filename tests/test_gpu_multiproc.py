@@ -30,6 +30,12 @@ def make_problem(kind):
     elif kind == "offdiag":
         p = P.offdiag_var(32)
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    elif kind == "offdiag_edge":
+        # Dxy away from zero on extrapolating faces: edge points read edge ghosts
+        p = P.offdiag_var(32)
+        p.bc = (1, 1, 1, 0, 1, 1)
+        p.Dxy = 0.05 + 0.1 * rng.uniform(0, 1, p.Dxy.shape)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
     elif kind in ("mixed32",):
         p = P.smooth_var(32, bc=(1, 0, 0, 1, 1, 1))
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
@@ -67,7 +73,7 @@ def run_ranks(world, kind, L, max_outer, eps, outdir, nproc=None):
 @gpu
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2), ("mixed", 1), ("mixed_generic", 2),
-                                    ("var", 3), ("mixed", 4)])
+                                    ("var", 3), ("mixed", 4), ("offdiag_edge", 2)])
 def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     from helpers import points, rel_l2
     from krylov_amd import capi
@@ -95,7 +101,8 @@ def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
 @gpu
 @pytest.mark.parametrize("nproc", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)])
 @pytest.mark.parametrize("kind,L", [("const", 2), ("var", 2), ("var", 1), ("offdiag", 2), ("mixed32", 2),
-                                    ("var_generic", 2), ("const_generic", 1), ("offdiag", 3)])
+                                    ("var_generic", 2), ("const_generic", 1), ("offdiag", 3), ("offdiag_edge", 2),
+                                    ("offdiag_edge", 1)])
 def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, nproc):
     """Sub-domains in x and y as well (the reference's mpi_manager_3D layout, up to its
     driver's 2 x 2 x 2): three passes against the undivided solve."""
