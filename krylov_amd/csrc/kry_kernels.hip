@@ -702,14 +702,15 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		}
 		if (GEN && cstore) a.Xout[pb + coff] = col_psi();   // sx, sy, ... still hold plane z
 		if (GEN && DEFER && nz >= 1) {
-			// l = 1: the reference writes u1 = A u0 over the old u1 (one array), and the x-face treatment of that
-			// output reads the array's ghost rows j = -1, my+1 (BoundaryHandler.C:420-421), which still hold the
-			// old u1.  Here the output goes to the partner buffer: hand it the old ghost rows (the xy edge ghosts
-			// derived from them are read by the 11-point operator).
+			// l = 1: the reference writes u1 = A u0 over the old u1 (one array), and the x- and y-face treatment
+			// of that output reads the array's ghost rows j = -1, my+1 and ghost planes (BoundaryHandler.C:420-421,
+			// 479-480), which still hold the old u1.  Here the output goes to the partner buffer: hand it the old
+			// ghost rows and planes (the xy edge ghosts derived from the rows are read by the 11-point operator).
+			const bool gplane = (z == -1 && !g.has_lo) || (z == g.mz + 1 && !g.has_hi);
 #pragma unroll
 			for (int e = 0; e < VD; ++e) {
 				const int j = y0 + w * VD + e;
-				if (j == -1 || j == g.my + 1) {
+				if (urow[e] && (gplane || j == -1 || j == g.my + 1)) {
 					if (uxx && uxy) st2(a.O + pb + off[e], nz1[DEFER ? e : 0]);
 					else if (uxx) a.O[pb + off[e]] = nz1[DEFER ? e : 0].x;
 					else if (uxy) a.O[pb + off[e] + 1] = nz1[DEFER ? e : 0].y;
@@ -1110,11 +1111,12 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 				st2s(a.w[0] + p, phv);
 				st2s(a.w[1] + p, r0);
 				if (GEN && L == 2) {
-					// r2' = r2 - tau12*r1 lives in registers only, except on the ghost rows j = -1, my+1: the x-face
-					// treatment of the next r2 = A r1 reads them from this array (BoundaryHandler.C:420-421), and the
-					// reference's array holds r2' there (solveLin_BICGStab.C:424 acts on all cells)
+					// r2' = r2 - tau12*r1 lives in registers only, except on the ghost rows j = -1, my+1 and the ghost
+					// planes: the face treatment of the next r2 = A r1 reads them from this array
+					// (BoundaryHandler.C:420-421, 479-480), and the reference's array holds r2' there
+					// (solveLin_BICGStab.C:424 acts on all cells)
 					const int row = (int)((q + QOFF) / a.g.px);
-					if (row == 0 || row == a.g.my + 2) st2(a.w[3] + p, r[i][2]);
+					if (row == 0 || row == a.g.my + 2 || z == -1 || z == a.g.mz + 1) st2(a.w[3] + p, r[i][2]);
 				}
 				if (GEN) {
 					if (cnt) {

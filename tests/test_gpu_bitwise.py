@@ -252,6 +252,34 @@ def test_high_contrast_mixed_faces_workload(orc, L):
     assert_identical(want, got, min_passes=40)
 
 
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("kind,bc", [("var", (0,) * 6), ("offdiag", (0,) * 6), ("const", (0,) * 6),
+                                     ("var", (1, 0, 1, 1, 0, 1)), ("offdiag", (1, 1, 0, 1, 1, 1)), ("const", (0, 1, 1, 0, 1, 1))])
+def test_start_vector_with_values_on_faces_and_ghosts(orc, kind, bc, L):
+    """A caller's phi that is not zero on the boundary planes and ghost cells: the field-coefficient
+    operator reads it as it stands (no input treatment, Krylov.C:407-496), the constant-coefficient
+    one treats it first (Krylov.C:516), and the whole-array updates carry its boundary values along."""
+    rng = np.random.default_rng(31)
+    if kind == "const":
+        p = P.reference_test1((24, 20, 28))
+        p.bc = bc
+    else:
+        p = (P.offdiag_var if kind == "offdiag" else P.smooth_var)((24, 20, 28), bc=bc)
+        if kind == "offdiag":
+            p.Dxy = 0.05 + 0.1 * rng.uniform(0, 1, p.Dxy.shape)
+    p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+    p.phi = rng.uniform(-1, 1, p.phi.shape)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=12)
+    assert got["fused"]
+    assert_identical(want, got, min_passes=5)
+    # ghost cells and boundary planes of the returned array too.  One cell is exempt: the ghost corner
+    # (-1,-1,-1), which no operator reads; the device's streaming kernels start behind it and return the
+    # caller's value there, the reference carries the whole-array updates through it.
+    g, w = got["phi"].copy(), want["phi"].copy()
+    g[0, 0, 0] = w[0, 0, 0] = 0.
+    assert np.array_equal(g, w)
+
+
 # ---- l > 2: one stencil kernel pair per BiCG step, one streaming kernel per Gram-Schmidt dot ----
 
 @pytest.mark.parametrize("L", [3, 4, 6])
