@@ -1454,7 +1454,8 @@ __global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const 
 	}
 }
 
-// BoundaryHandler3D::do_BCs, rim = 1 (BoundaryHandler.C:416-568); one launch per direction.
+// BoundaryHandler3D::do_BCs, rim = 1 (BoundaryHandler.C:416-568); one direction per launch
+// (the solver runs x and y through g_bc_xy and only the z faces of the generic path through this one).
 // dir 0: a thread per (j,k) in [-1..my+1] x [-1..mz+1]
 // dir 1: a thread per (i,k) in [0..mx] x [-1..mz+1]
 // dir 2: a thread per (i,j) in [0..mx] x [0..my]; only on faces of the global domain
@@ -1511,6 +1512,47 @@ __global__ void g_bc(double *d, KryGeo g, int dir)
 		if (!g.has_hi) {
 			if (g.bc[5] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
 			else if (g.bc[5] == 1) {
+				c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
+				c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
+			}
+		}
+	}
+}
+
+// The x faces and then the y faces of one plane per block: both treatments stay inside the plane
+// (BoundaryHandler.C:416-517), and the y treatment reads columns 0 and mx as the x treatment left
+// them, so the block's threads meet at a barrier in between.
+__global__ __launch_bounds__(NT) void g_bc_xy(double *d, KryGeo g)
+{
+	const int k = (int)blockIdx.x - 1;
+	for (int j = (int)threadIdx.x - 1; j <= g.my + 1; j += NT) {
+		double *row = d + kry_idx(g, 0, j, k);   // row[i] = value at grid index i
+		if (!g.nb[0]) {
+			if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
+			else if (g.bc[0] == 1) row[-1] = 2. * row[0] - row[1];
+		}
+		const int m = g.mx;
+		if (!g.nb[1]) {
+			if (g.bc[1] == 0) { row[m] = 0.; row[m + 1] = 0.; }
+			else if (g.bc[1] == 1) {
+				row[m] = 2. * row[m - 1] - row[m - 2];
+				row[m + 1] = 2. * row[m] - row[m - 1];
+			}
+		}
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (int i = (int)threadIdx.x; i <= g.mx; i += NT) {
+		double *c = d + kry_idx(g, i, 0, k);     // c[j*px]
+		const long s = g.px;
+		if (!g.nb[2]) {
+			if (g.bc[2] == 0) { c[-s] = 0.; c[0] = 0.; }
+			else if (g.bc[2] == 1) c[-s] = 2. * c[0] - c[s];
+		}
+		const int m = g.my;
+		if (!g.nb[3]) {
+			if (g.bc[3] == 0) { c[m * s] = 0.; c[(m + 1) * s] = 0.; }
+			else if (g.bc[3] == 1) {
 				c[m * s] = 2. * c[(m - 1) * s] - c[(m - 2) * s];
 				c[(m + 1) * s] = 2. * c[m * s] - c[(m - 1) * s];
 			}
@@ -1779,8 +1821,7 @@ hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n,
 
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs)
 {
-	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.my + 3, 64), g.mz + 3), dim3(64), 0, st, d, g, 0);
-	hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.mz + 3), dim3(64), 0, st, d, g, 1);
+	hipLaunchKernelGGL(g_bc_xy, dim3(g.mz + 3), dim3(NT), 0, st, d, g);
 	if (ndirs > 2) hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
 	return hipGetLastError();
 }
