@@ -234,7 +234,7 @@ def test_edge_ghosts_with_offdiagonal_term_away_from_zero(orc, bc, L):
     want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20)
     assert got["path"] == 2
     assert_identical(want, got, min_passes=5)
-    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20, nslabs=2)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=20, nslabs=2, split=True)
     assert got["path"] == 2
     assert_identical(want, got, min_passes=5)
 
@@ -278,6 +278,12 @@ def test_start_vector_with_values_on_faces_and_ghosts(orc, kind, bc, L):
     g, w = got["phi"].copy(), want["phi"].copy()
     g[0, 0, 0] = w[0, 0, 0] = 0.
     assert np.array_equal(g, w)
+    # two slabs, and one kernel per primitive (which has no exempt cell)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=12, nslabs=2, split=True)   # (overlapped exchange is the default)
+    assert_identical(want, got, min_passes=5)
+    want, got = run_pair(orc, p, L, eps=1e-13, max_outer=12, flags=capi.KRY_FORCE_GENERIC)
+    assert_identical(want, got, min_passes=5)
+    assert np.array_equal(got["phi"], want["phi"])
 
 
 # ---- l > 2: one stencil kernel pair per BiCG step, one streaming kernel per Gram-Schmidt dot ----
