@@ -49,6 +49,8 @@ def kernel_words(L, var, offd):
         return {0: 7 + d,          # r0,u0,u1(old),lam,rt -> u0,u1
                 3: 5 + d,          # r0,u1,lam -> r0,r1
                 7: 7}              # phi,u0,r0,r1,rt -> phi,r0   (the u0 update rides in the next pass's first kernel)
+    if L > 2:
+        return {}                  # the timing slots of l > 2 hold several kernels each: no per-kernel table
     return {0: 6 + d,              # r0,u0,lam,rt -> u0,u1
             2: 6 + d,              # r0,u1,lam,rt -> r0,r1
             1: 6 + d,              # r1,u1,lam,rt -> u1,u2
@@ -59,7 +61,17 @@ def kernel_words(L, var, offd):
 
 def contract_words(L, var):
     """Doubles per point and pass of the fully fused schedule the metric's byte model is defined on."""
+    if L > 2:
+        return moved_words(L, var)  # no contract figure exists for l > 2: the words the kernels move
     return {1: (26 if var else 20), 2: (62 if var else 50)}[L]
+
+
+def moved_words(L, var):
+    """Doubles per point and pass the kernels move."""
+    if L > 2:
+        # 2l stencil kernels, the pointwise sweeps (3 l^2), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
+        return 2 * L * (9 if var else 6) + 5 * L * L + 2 * L + 7
+    return sum(kernel_words(L, var, False).values())
 
 
 def measured_traffic(kernel_name, n, L, workload, world):
@@ -297,7 +309,7 @@ def single_gpu_passes(capi, device, n, L, workload, steps, warmup, fields=None):
         hist = s.history()
     npts = float(n + 1) ** 3
     kern = kernel_table(a, b, L, var, npts)
-    moved = sum(kernel_words(L, var, False).values())
+    moved = moved_words(L, var)
     ms = dt / steps * 1e3
     return {"workload": "%d^3 fp64 %s-coefficient, l=%d, Dirichlet faces" % (n, "variable" if var else "constant", L),
             "value": round(steps / dt, 2), "unit": "iter/s", "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
@@ -613,7 +625,7 @@ def main():
                 roof["traffic_source"] = "profiles/" + src
         ms_step = elapsed / args.steps * 1e3
         W = contract_words(L, var)
-        moved = sum(kernel_words(L, var, False).values())
+        moved = moved_words(L, var)
         whole = 8.0 * W * npts / (ms_step * 1e-3) / 1e9
         whole_moved = 8.0 * moved * npts / (ms_step * 1e-3) / 1e9
         # share of a pass spent exchanging (rank 0): mapped-memory routes over the timed region
