@@ -8,7 +8,9 @@
 #ifndef KRY_SEG
 #define KRY_SEG 2048  // doubles of a plane handled per block and plane by the streaming kernels
 #endif
+#ifndef KRY_SURF_BLOCKS
 #define KRY_SURF_BLOCKS 512    // largest grid of the boundary-plane dot kernel
+#endif
 
 // fused stencil kernel kinds
 enum KryFusedKind {
