@@ -69,8 +69,8 @@ def contract_words(L, var):
 def moved_words(L, var):
     """Doubles per point and pass the kernels move."""
     if L > 2:
-        # 2l stencil kernels, the pointwise sweeps (3 l^2), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
-        return 2 * L * (9 if var else 6) + 5 * L * L + 2 * L + 7
+        # 2l stencil kernels, the pointwise sweeps (2 l^2 + l - 3), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
+        return 2 * L * (9 if var else 6) + 4 * L * L + 3 * L + 4
     return sum(kernel_words(L, var, False).values())
 
 

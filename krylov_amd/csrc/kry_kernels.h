@@ -56,16 +56,11 @@ struct KryFused {
 	int blk_off;             // offset of this launch's blocks in the partial-sum array
 };
 
-// coefficient of a pointwise update, taken from the device-resident recurrences
-enum KryCoef { KC_NBETA = 0, KC_NALPHA, KC_ALPHA };
-// dst = x + y*c for a list of vector triples, applied in order point by point (general l)
-struct KryOps {
-	int n;
-	struct {
-		double *dst;
-		const double *x, *y;
-		int coef;
-	} op[2 * KRY_LMAX];
+// pointwise statements of BiCG step jj > 0 of the general-l pass: the current copies of r_0..r_jj-1 and u_0..u_jj
+struct KryPointN {
+	int jj;
+	double *r[KRY_LMAX];
+	double *u[KRY_LMAX + 1];
 };
 
 struct KryStream {
@@ -89,7 +84,8 @@ hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);
 hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStream_t st);
 // general l (l > 2): pointwise updates, one Gram-Schmidt step, end of pass
-hipError_t kry_launch_axpyn(const KryStream &a, const KryOps &ops, int nbx, int nby, hipStream_t st);
+//   w[0] = phi
+hipError_t kry_launch_bicgn(const KryStream &a, const KryPointN &f, int nbx, int nby, hipStream_t st);
 //   v[0] = w[0] = r_jj, v[1] = r_ii' of the pending update (iip > 0), v[2] = r_ii of the dot (last == 0) or r_0 (last)
 hipError_t kry_launch_mgsn(const KryStream &a, int jj, int iip, int last, int nbx, int nby, hipStream_t st);
 //   r = r_0..r_L, u = u_0..u_L, v[0] = r~, w[0] = phi; r_0 and u_0 are updated in place

@@ -1,7 +1,7 @@
 // gfx950 kernels of the BiCGStab(l) stencil solver.
 //
 // Two families:
-//   * fused kernels (k_fused, k_surf, k_mgs2, k_final; k_axpyn, k_mgsn, k_finaln for
+//   * fused kernels (k_fused, k_surf, k_mgs2, k_final; k_bicgn, k_mgsn, k_finaln for
 //     l > 2): LDS-tiled, z-marching stencil fused with the vector update that produces
 //     its input and with the dot products that consume its output; wave64 shuffles + a
 //     single-pass grid reduction whose last block also advances the scalar recurrences.
@@ -1145,30 +1145,59 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 // segments x plane groups, per-thread sums in the same order), scalars from the device state
 // ---------------------------------------------------------------------------
 
-// Pointwise statements of a BiCG step that no stencil kernel carries
-// (solveLin_BICGStab.C:356-362 and 392-394 for ii < jj, :403): dst = x + y*c per listed triple.
-__global__ __launch_bounds__(NT) void k_axpyn(const KryStream a, const KryOps ops)
+// Pointwise statements of BiCG step jj > 0 that no stencil kernel carries, each array read and written once:
+//   phi += alpha_(jj-1)*u_0      (solveLin_BICGStab.C:403 of the previous step; u_0 is still that step's)
+//   u_ii = r_ii - beta*u_ii      (:356-362, ii < jj; ii = jj is done by the A kernel)
+//   r_ii -= alpha*u_(ii+1)       (:392-394, ii < jj; ii = jj is done by the B kernel)
+// The chain runs upwards in ii with the updated u_(ii+1) formed one step ahead.
+__global__ __launch_bounds__(NT) void k_bicgn(const KryStream a, const KryPointN f)
 {
 	const KryState *S = a.S;
 	if (S->done) return;
 	constexpr int UN = SEG2 / NT;
-	const double nbeta = -S->beta, nalpha = -S->alpha, alpha = S->alpha;
+	const int jj = f.jj;
+	const double nbeta = -S->beta, nalpha = -S->alpha, aprev = S->alpha0;
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const long pb = (long)(a.zfirst + pl + 1) * a.g.ps + QOFF;
-		for (int o = 0; o < ops.n; ++o) {
-			const double c = ops.op[o].coef == KC_NBETA ? nbeta : (ops.op[o].coef == KC_NALPHA ? nalpha : alpha);
-			double2 x[UN], y[UN];
+		double2 un[UN], ro[UN];
+		{
+			double2 ph[UN], uo[UN];
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long p = pb + q0 + 2L * i * NT;
-				x[i] = ld2s(ops.op[o].x + p);
-				y[i] = ld2s(ops.op[o].y + p);
+				ph[i] = ld2s(a.w[0] + p);
+				uo[i] = ld2s(f.u[0] + p);
+				ro[i] = ld2s(f.r[0] + p);
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long q = q0 + 2L * i * NT;
-				if (q < a.g.ps) st2s(ops.op[o].dst + pb + q, axpy2(x[i], y[i], c));
+				ph[i] = axpy2(ph[i], uo[i], aprev);
+				un[i] = axpy2(ro[i], uo[i], nbeta);
+				if (q < a.g.ps) st2s(a.w[0] + pb + q, ph[i]);
+			}
+		}
+		for (int ii = 0; ii < jj; ++ii) {
+			const bool more = ii + 1 < jj;
+			double2 nx[UN], rn[UN];
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long p = pb + q0 + 2L * i * NT;
+				nx[i] = ld2s(f.u[ii + 1] + p);
+				if (more) rn[i] = ld2s(f.r[ii + 1] + p);
+			}
+#pragma unroll
+			for (int i = 0; i < UN; ++i) {
+				const long q = q0 + 2L * i * NT;
+				if (more) nx[i] = axpy2(rn[i], nx[i], nbeta);          // the updated u_(ii+1)
+				const double2 rnew = axpy2(ro[i], nx[i], nalpha);
+				if (q < a.g.ps) {
+					st2s(f.u[ii] + pb + q, un[i]);
+					st2s(f.r[ii] + pb + q, rnew);
+				}
+				un[i] = nx[i];
+				if (more) ro[i] = rn[i];
 			}
 		}
 	}
@@ -1244,7 +1273,7 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 }
 
 // End of an outer pass for any l (solveLin_BICGStab.C:450-464), statement by statement:
-//   phi += gamma_1*r_0; r_0 -= gammap_L*r_L; u_0 -= gamma_L*u_L;
+//   phi += alpha*u_0 (:403 of the last BiCG step); phi += gamma_1*r_0; r_0 -= gammap_L*r_L; u_0 -= gamma_L*u_L;
 //   for jj = 1..L-1: u_0 -= gamma_jj*u_jj; phi += gammapp_jj*r_jj; r_0 -= gammap_jj*r_jj;
 //   |r_0|^2 (norm weights) and (r_0, r~).
 template <bool GEN>
@@ -1268,7 +1297,7 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
 		double2 ph[UN], r0[UN], u0[UN], rt[UN];
 		{
-			const double g1 = S->gamma[1], gpL = S->gammap[L], gL = S->gamma[L];
+			const double alpha = S->alpha, g1 = S->gamma[1], gpL = S->gammap[L], gL = S->gamma[L];
 			double2 rl[UN], ul[UN];
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
@@ -1282,6 +1311,7 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
+				ph[i] = axpy2(ph[i], u0[i], alpha);
 				ph[i] = axpy2(ph[i], r0[i], g1);
 				r0[i] = axpy2(r0[i], rl[i], -gpL);
 				u0[i] = axpy2(u0[i], ul[i], -gL);
@@ -1738,9 +1768,9 @@ hipError_t kry_launch_final(int L, const KryStream &a, int nbx, int nby, hipStre
 	return hipGetLastError();
 }
 
-hipError_t kry_launch_axpyn(const KryStream &a, const KryOps &ops, int nbx, int nby, hipStream_t st)
+hipError_t kry_launch_bicgn(const KryStream &a, const KryPointN &f, int nbx, int nby, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_axpyn, dim3(nbx, nby), dim3(NT), 0, st, a, ops);
+	hipLaunchKernelGGL(k_bicgn, dim3(nbx, nby), dim3(NT), 0, st, a, f);
 	return hipGetLastError();
 }
 

@@ -718,25 +718,24 @@ int fused_pass_general(kry_solver *h, int it)
 			}));
 			CHK(reduce_sums(h, PH_A));
 		}
-		// :356-362 and :392-394 for ii < jj, :403
-		CHK(for_slabs([&](Slab &s, int) -> int {
-			int nbx, nby;
-			KryStream a = stream_base(h, s, PH_NONE, &nbx, &nby, 1);
-			KryOps ops;
-			ops.n = 0;
-			auto add = [&](double *dst, const double *x, const double *y, int coef) {
-				ops.op[ops.n].dst = dst; ops.op[ops.n].x = x; ops.op[ops.n].y = y; ops.op[ops.n].coef = coef;
-				++ops.n;
-			};
-			for (int ii = 0; ii < jj; ++ii) add(s.ub[ii][cu[ii]].p, s.rb[ii][cr[ii]].p, s.ub[ii][cu[ii]].p, KC_NBETA);
-			for (int ii = 0; ii < jj; ++ii) add(s.rb[ii][cr[ii]].p, s.rb[ii][cr[ii]].p, s.ub[ii + 1][cu[ii + 1]].p, KC_NALPHA);
-			add(s.phi.p, s.phi.p, s.ub[0][cu[0]].p, KC_ALPHA);
-			HIPCHK(hipSetDevice(s.device));
-			prof_begin(h, s, 6);
-			HIPCHK(kry_launch_axpyn(a, ops, nbx, nby, s.st));
-			prof_end(h, s);
-			return 0;
-		}));
+		// :356-362 and :392-394 for ii < jj, and :403 of the step before (the last step's rides in the end-of-pass kernel)
+		if (jj > 0) {
+			CHK(for_slabs([&](Slab &s, int) -> int {
+				int nbx, nby;
+				KryStream a = stream_base(h, s, PH_NONE, &nbx, &nby, 1);
+				KryPointN f;
+				memset(&f, 0, sizeof f);
+				f.jj = jj;
+				for (int ii = 0; ii < jj; ++ii) f.r[ii] = s.rb[ii][cr[ii]].p;
+				for (int ii = 0; ii <= jj; ++ii) f.u[ii] = s.ub[ii][cu[ii]].p;
+				a.w[0] = s.phi.p;
+				HIPCHK(hipSetDevice(s.device));
+				prof_begin(h, s, 6);
+				HIPCHK(kry_launch_bicgn(a, f, nbx, nby, s.st));
+				prof_end(h, s);
+				return 0;
+			}));
+		}
 		{
 			const int from = cr[jj];
 			flip(cr, jj);
@@ -2024,9 +2023,9 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	if (h->L == 1) W = h->var ? (h->offd ? 28 : 26) : 20;
 	else if (h->L == 2) W = h->var ? (h->offd ? 66 : 62) : 50;
 	else {
-		// 2l stencil kernels, the pointwise sweeps (3 l^2), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
+		// 2l stencil kernels, the pointwise sweeps (2 l^2 + l - 3), the Gram-Schmidt kernels (2 l^2), the end of the pass (2l + 7)
 		const int per_stencil = h->var ? (h->offd ? 10 : 9) : 6;
-		W = 2 * h->L * per_stencil + 5 * h->L * h->L + 2 * h->L + 7;
+		W = 2 * h->L * per_stencil + 4 * h->L * h->L + 3 * h->L + 4;
 	}
 	const double npts = ((double)h->d.mx[0] * h->np[0] + 1) * ((double)h->d.mx[1] * h->np[1] + 1) *
 	                    ((double)h->mzl * h->d.nslabs + 1);

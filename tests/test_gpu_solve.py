@@ -160,11 +160,11 @@ def test_fields_may_live_in_device_memory(orc):
     assert np.array_equal(phi, ref["phi"])
 
 
-@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("L", [1, 2, 3])
 def test_graph_replay_of_pass_pairs_changes_nothing(monkeypatch, L):
     """KRY_GRAPH=1 replays two captured passes per launch call; odd starts, odd
     batch lengths and the tail fall back to plain launches.  Same bits either way."""
-    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1)) if L == 2 else P.reference_test1(24)
+    p = P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1)) if L >= 2 else P.reference_test1(24)
     plain = capi.solve_problem(p, L=L, eps=1e-9)
     monkeypatch.setenv("KRY_GRAPH", "1")
     graph = capi.solve_problem(p, L=L, eps=1e-9)
