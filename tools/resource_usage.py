@@ -12,7 +12,7 @@ SRC = os.path.join(ROOT, "krylov_amd", "csrc", "kry_kernels.hip")
 
 
 def main():
-    want = sys.argv[1:] or ["k_fused", "k_final", "k_mgs", "k_axpyn", "k_surf", "k_halo", "g_"]
+    want = sys.argv[1:] or ["k_fused", "k_final", "k_mgs", "k_bicgn", "k_surf", "k_halo", "g_"]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
            "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", "/dev/null"]
     txt = subprocess.run(cmd, capture_output=True, text=True).stderr
