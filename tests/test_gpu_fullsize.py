@@ -153,3 +153,23 @@ def test_benchmark_grids_first_passes_against_the_oracle_bit_for_bit(orc, n, wor
     assert got["norm_rhs"] == want["norm_rhs"] and got["norm_init"] == want["norm_init"]
     assert np.max(np.abs(got["history"] - want["history"]) / want["norm_rhs"]) <= 1e-15
     assert np.array_equal(points(got["phi"]), points(want["phi"]))
+
+
+def test_weak_scaling_block_first_pass_against_the_oracle_bit_for_bit(orc):
+    """The 1024 x 1024 x 128 block a GPU holds in the weak-scaling configuration (eight tiles per
+    row, rows of 1040 doubles): one pass of the l = 2 solve, device against oracle in device order."""
+    import bench
+    f = bench.slab_problem(1024, 1, 0, "var", nz=128)
+    p = P.Problem("weak block", f["mx"], f["delx"], f["bc"], True, False, (1., 1., 1.), f["phi"], f["rhs"], f["lam"],
+                  f["Dxx"], f["Dyy"], f["Dzz"], np.zeros_like(f["phi"]))
+    got = capi.solve_problem(p, L=2, eps=0.0, max_outer=1)
+    ty, zc, sb = got["order"]
+    orc.use_gpu_order(1, ty, zc, sb)
+    try:
+        want = oracle_solve(orc, p, L=2, eps=0.0, max_outer=1)
+    finally:
+        orc.use_gpu_order(0)
+    assert got["iters"] == want["iters"] == 1
+    assert got["norm_rhs"] == want["norm_rhs"] and got["norm_init"] == want["norm_init"]
+    assert np.array_equal(got["history"], want["history"])
+    assert np.array_equal(points(got["phi"]), points(want["phi"]))
