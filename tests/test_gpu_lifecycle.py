@@ -55,3 +55,27 @@ def test_failed_create_leaves_nothing_behind():
             capi.Solver((32, 32, 30), (1 / 32.,) * 3, (0,) * 6, L=2, nslabs=4, slab_begin=0, slab_count=4,
                         devices=(0, 0, 0, 0))                                   # 30 planes do not divide into 4 slabs
     assert abs(free_bytes() - before) <= 8 << 20
+
+
+def test_independent_handles_on_concurrent_host_threads():
+    """The reference's solver objects are independent of each other; so are handles: four host
+    threads, each with a handle of its own on the same GPU, obtain the bits of a serial run."""
+    import threading
+    probs = [(P.reference_test1(32), 2), (P.smooth_var(32), 1), (P.smooth_var(24, bc=(0, 0, 1, 1, 0, 1)), 2),
+             (P.offdiag_var(24), 3)]
+    serial = [capi.solve_problem(p, L=L, eps=1e-8) for p, L in probs]
+    out = [None] * len(probs)
+
+    def work(k):
+        p, L = probs[k]
+        for _ in range(3):
+            out[k] = capi.solve_problem(p, L=L, eps=1e-8)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(probs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=200)
+    for a, b in zip(serial, out):
+        assert b is not None and b["status"] == a["status"] == 0
+        assert np.array_equal(a["history"], b["history"]) and np.array_equal(a["phi"], b["phi"])
