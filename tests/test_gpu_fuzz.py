@@ -1,0 +1,76 @@
+"""Randomised whole-solve parity: grid extents (odd, tiny, wider than a tile), spacings, face
+types, coefficient kind, l, slab count and every field drawn from a seeded generator; the device
+against the oracle summing in the device's order, bit for bit -- history, pass count, and the
+returned array including boundary planes and ghost cells (one ghost corner exempt, see
+test_start_vector_with_values_on_faces_and_ghosts in test_gpu_bitwise.py)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_solve, points
+from krylov_amd import capi, problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    wide = rng.integers(0, 6) == 0
+    mx = (int(rng.integers(129, 150)) if wide else int(rng.integers(4, 41)), int(rng.integers(4, 41)), int(rng.integers(4, 33)))
+    nslabs = 1
+    if rng.integers(0, 3) == 0:
+        for c in (4, 2):
+            if mx[2] % c == 0 and mx[2] // c >= 4:
+                nslabs = c
+                break
+    dyadic = rng.integers(0, 2) == 0
+    delx = tuple((1.0 / 2 ** int(rng.integers(3, 7))) if dyadic else float(rng.uniform(0.01, 0.2)) for _ in range(3))
+    bc = tuple(int(b) for b in rng.integers(0, 2, 6))
+    if rng.integers(0, 4) == 0:
+        bc = (0,) * 6
+    kind = ("const", "var", "offdiag")[int(rng.integers(0, 3))]
+    L = int(rng.integers(1, 5))
+    shp = (mx[2] + 3, mx[1] + 3, mx[0] + 3)
+    u = lambda lo, hi: rng.uniform(lo, hi, shp)
+    p = P.Problem("fuzz %d" % seed, mx, delx, bc, kind != "const", kind == "offdiag",
+                  tuple(float(v) for v in rng.uniform(0.5, 3.0, 3)), u(-1, 1), u(-1, 1), u(0, 2),
+                  u(0.5, 2), u(0.5, 2), u(0.5, 2), u(-0.2, 0.2) if kind == "offdiag" else np.zeros(shp))
+    return p, L, nslabs
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_configuration(orc, seed):
+    check(orc, seed, False)
+
+
+@pytest.mark.parametrize("seed", range(0, 200, 4))
+def test_random_configuration_one_kernel_per_primitive(orc, seed):
+    check(orc, seed, True)
+
+
+def check(orc, seed, generic):
+    p, L, nslabs = draw(seed)
+    got = capi.solve_problem(p, L=L, eps=1e-13, max_outer=6, nslabs_local=nslabs, devices=(0,),
+                             flags=capi.KRY_FORCE_GENERIC if generic else 0)
+    ty, zc, sb = got["order"]
+    orc.use_gpu_order({0: 2, 1: 1, 2: 3}[got["path"]], ty, zc, sb)
+    orc.gpu_order_slabs(nslabs, True)
+    try:
+        want = oracle_solve(orc, p, L=L, eps=1e-13, max_outer=6)
+    finally:
+        orc.gpu_order_slabs(1, False)
+        orc.use_gpu_order(0)
+    what = "%s mx=%s bc=%s l=%d slabs=%d path=%d" % (p.name, p.mx, p.bc, L, nslabs, got["path"])
+    assert (got["path"] == 0) if generic else (got["path"] in (1, 2)), what
+    assert got["status"] == want["status"], what
+    assert got["iters"] == want["iters"], what
+    assert got["norm_rhs"] == want["norm_rhs"] and got["norm_init"] == want["norm_init"], what
+    hw, hg = want["history"], got["history"]
+    if np.all(np.isfinite(hw)):
+        assert np.array_equal(hg, hw), what
+        assert np.array_equal(points(got["phi"]), points(want["phi"])), what
+        g, w = got["phi"].copy(), want["phi"].copy()
+        if not generic:
+            g[0, 0, 0] = w[0, 0, 0] = 0.
+        assert np.array_equal(g, w), what
+    else:
+        assert np.array_equal(np.isfinite(hg), np.isfinite(hw)), what
