@@ -47,13 +47,26 @@ def test_random_configuration_one_kernel_per_primitive(orc, seed):
     check(orc, seed, True)
 
 
-def check(orc, seed, generic):
+@pytest.mark.parametrize("seed", range(200, 320))
+def test_random_configuration_and_random_tiling(orc, monkeypatch, seed):
+    """The same with the kernels' tiling drawn as well: chunk depth, tile rows, blocks of the streaming
+    kernels, and the split launches of the overlapped exchange on or off."""
+    rng = np.random.default_rng(5000 + seed)
+    monkeypatch.setenv("KRY_ZC", str(int(rng.choice([2, 3, 5, 8, 13]))))
+    monkeypatch.setenv("KRY_TY", str(int(rng.choice([8, 16]))))
+    monkeypatch.setenv("KRY_STREAM_BLOCKS", str(int(rng.choice([64, 256, 2048]))))
+    overlap = int(rng.integers(0, 2))
+    monkeypatch.setenv("KRY_OVERLAP", str(overlap))
+    check(orc, seed, False, split=bool(overlap))
+
+
+def check(orc, seed, generic, split=True):
     p, L, nslabs = draw(seed)
     got = capi.solve_problem(p, L=L, eps=1e-13, max_outer=6, nslabs_local=nslabs, devices=(0,),
                              flags=capi.KRY_FORCE_GENERIC if generic else 0)
     ty, zc, sb = got["order"]
     orc.use_gpu_order({0: 2, 1: 1, 2: 3}[got["path"]], ty, zc, sb)
-    orc.gpu_order_slabs(nslabs, True)
+    orc.gpu_order_slabs(nslabs, split)
     try:
         want = oracle_solve(orc, p, L=L, eps=1e-13, max_outer=6)
     finally:
