@@ -87,3 +87,33 @@ def check(orc, seed, generic, split=True):
         assert np.array_equal(g, w), what
     else:
         assert np.array_equal(np.isfinite(hg), np.isfinite(hw)), what
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["const", "var", "offdiag"])
+@pytest.mark.parametrize("bc", [(0,) * 6, (1,) * 6, (0, 1, 1, 0, 1, 0)])
+@pytest.mark.parametrize("mx", [(4, 4, 4), (4, 5, 6), (6, 4, 5), (5, 9, 4), (130, 4, 4)])
+def test_smallest_grids(orc, mx, bc, kind, L):
+    """Four intervals per direction is the smallest grid the library takes."""
+    rng = np.random.default_rng(7)
+    shp = (mx[2] + 3, mx[1] + 3, mx[0] + 3)
+    u = lambda lo, hi: rng.uniform(lo, hi, shp)
+    p = P.Problem("tiny", mx, (0.1, 0.2, 0.25), bc, kind != "const", kind == "offdiag", (1., 2., 3.), u(-1, 1), u(-1, 1), u(0, 2),
+                  u(.5, 2), u(.5, 2), u(.5, 2), u(-.2, .2) if kind == "offdiag" else np.zeros(shp))
+    got = capi.solve_problem(p, L=L, eps=1e-13, max_outer=4)
+    ty, zc, sb = got["order"]
+    orc.use_gpu_order({0: 2, 1: 1, 2: 3}[got["path"]], ty, zc, sb)
+    try:
+        want = oracle_solve(orc, p, L=L, eps=1e-13, max_outer=4)
+    finally:
+        orc.use_gpu_order(0)
+    assert got["iters"] == want["iters"] and got["status"] == want["status"]
+    hw, hg = want["history"], got["history"]
+    assert np.array_equal(np.isfinite(hw), np.isfinite(hg))
+    if np.all(np.isfinite(hw)):
+        assert np.array_equal(hw, hg) and np.array_equal(points(got["phi"]), points(want["phi"]))
+
+
+def test_grids_below_four_intervals_are_refused():
+    with pytest.raises(capi.KryError, match="bad grid"):
+        capi.Solver((3, 8, 8), (0.1, 0.1, 0.1), (0,) * 6, L=2)
