@@ -53,7 +53,8 @@ enum {
 
 typedef struct kry_desc {
 	int    mx[3];          /* last grid-point index of the host fields, per direction
-	                          (grid_1D::get_mx, BICGStab3D/solveLin_BICGStab.C:165-167) */
+	                          (grid_1D::get_mx, BICGStab3D/solveLin_BICGStab.C:165-167); at least 4,
+	                          per slab too (smaller grids: KRY_ERR_ARG) */
 	double delx[3];        /* grid spacing (grid_1D::get_del, solveLin_BICGStab.C:161-163) */
 	int    bc_type[6];     /* xlo,xhi,ylo,yhi,zlo,zhi of the GLOBAL domain: 0 Dirichlet,
 	                          1 linear extrapolation ("Neumann"), other: untouched
