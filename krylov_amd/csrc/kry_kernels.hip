@@ -551,6 +551,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		const int nb = a.nblk, b = blockIdx.x;
 		const int q = nb >> 3, r = nb & 7, x = b & 7;
 		bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+		if (a.rev) bid = nb - 1 - bid;
 	}
 	const int tx = bid % a.ntx;
 	const int ty = (bid / a.ntx) % a.nty;

@@ -742,6 +742,7 @@ int fused_pass_general(kry_solver *h, int it)
 			const int phase = (jj < L - 1) ? PH_B : PH_BN;
 			CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 				KryFused a = fused_base(h, s, phase);
+				a.rev = 1;
 				a.X = s.rb[jj][from].p; a.Y = s.ub[jj + 1][cu[jj + 1]].p; a.Xout = s.rb[jj][cr[jj]].p;
 				a.O = s.rb[jj + 1][cr[jj + 1]].p;
 				return a;
@@ -824,6 +825,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- B (last): r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
 		CHK(stencil_step(h, KF_B0L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL1);
+			a.rev = 1;
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][q].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][0].p;
 			return a;
@@ -833,6 +835,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 		CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_B);
+			a.rev = 1;
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][p].p;
 			return a;
@@ -849,6 +852,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 1, B (last): r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r2,r1)
 		CHK(stencil_step(h, KF_B1L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL2);
+			a.rev = 1;
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
 			a.O = s.rb[2][0].p;
 			return a;
