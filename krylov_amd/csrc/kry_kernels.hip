@@ -1553,10 +1553,10 @@ __global__ void g_bc(double *d, KryGeo g, int dir)
 // The x faces and then the y faces of one plane per block: both treatments stay inside the plane
 // (BoundaryHandler.C:416-517), and the y treatment reads columns 0 and mx as the x treatment left
 // them, so the block's threads meet at a barrier in between.
-__global__ __launch_bounds__(NT) void g_bc_xy(double *d, KryGeo g)
+__global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
 {
 	const int k = (int)blockIdx.x - 1;
-	for (int j = (int)threadIdx.x - 1; j <= g.my + 1; j += NT) {
+	for (int j = (int)threadIdx.x - 1; j <= g.my + 1; j += (int)blockDim.x) {
 		double *row = d + kry_idx(g, 0, j, k);   // row[i] = value at grid index i
 		if (!g.nb[0]) {
 			if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(NT) void g_bc_xy(double *d, KryGeo g)
 	}
 	__threadfence_block();
 	__syncthreads();
-	for (int i = (int)threadIdx.x; i <= g.mx; i += NT) {
+	for (int i = (int)threadIdx.x; i <= g.mx; i += (int)blockDim.x) {
 		double *c = d + kry_idx(g, i, 0, k);     // c[j*px]
 		const long s = g.px;
 		if (!g.nb[2]) {
@@ -1852,7 +1852,9 @@ hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n,
 
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs)
 {
-	hipLaunchKernelGGL(g_bc_xy, dim3(g.mz + 3), dim3(NT), 0, st, d, g);
+	// one sweep of the block over the rows, one over the columns where the plane allows it
+	const int nt = std::min(1024, std::max(NT, ((std::max(g.mx + 1, g.my + 3) + 63) / 64) * 64));
+	hipLaunchKernelGGL(g_bc_xy, dim3(g.mz + 3), dim3(nt), 0, st, d, g);
 	if (ndirs > 2) hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
 	return hipGetLastError();
 }
