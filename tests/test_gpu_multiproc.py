@@ -98,20 +98,20 @@ def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     assert np.array_equal(parts[0]["hist"], same["history"])
 
 
+ALL_SPLITS = [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)]
+# three kinds on every split, the others on the x-y split and the full split (one of them on the full split only)
+CART_CASES = [(k, L, n) for (k, L) in (("var", 2), ("mixed32", 2), ("offdiag", 2)) for n in ALL_SPLITS] + \
+             [(k, L, n) for (k, L) in (("const", 2), ("var", 1), ("var_generic", 2), ("offdiag", 3), ("offdiag_edge", 2),
+                                       ("offdiag_edge", 1)) for n in ((2, 2, 1), (2, 2, 2))] + [("const_generic", 1, (2, 2, 2))]
+
+
 @gpu
-@pytest.mark.parametrize("nproc", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)])
-@pytest.mark.parametrize("kind,L", [("const", 2), ("var", 2), ("var", 1), ("offdiag", 2), ("mixed32", 2),
-                                    ("var_generic", 2), ("const_generic", 1), ("offdiag", 3), ("offdiag_edge", 2),
-                                    ("offdiag_edge", 1)])
+@pytest.mark.parametrize("kind,L,nproc", CART_CASES)
 def test_cartesian_split_reproduces_the_single_process_solve(tmp_path, kind, L, nproc):
     """Sub-domains in x and y as well (the reference's mpi_manager_3D layout, up to its
     driver's 2 x 2 x 2): three passes against the undivided solve."""
     from helpers import points
     from krylov_amd import capi
-    if kind == "const_generic" and nproc != (2, 2, 2):
-        pytest.skip("covered by the 2 x 2 x 2 case")
-    if (kind, L) not in (("var", 2), ("mixed32", 2), ("offdiag", 2)) and nproc not in ((2, 2, 1), (2, 2, 2)):
-        pytest.skip("this kind runs on the x-y split and the full split")
     p = make_problem(kind)
     flags = capi.KRY_FORCE_GENERIC if kind.endswith("_generic") else 0
     one = capi.solve_problem(p, L=L, eps=1e-30, max_outer=3, flags=flags)
