@@ -200,7 +200,11 @@ int kry_solve_var(kry_handle h, double *phi, const double *rhs, const double *la
  * solves to convergence): kry_load_* stages the fields and runs the prologue of
  * solve_int (solveLin_BICGStab.C:268-320); kry_iterate runs up to n_outer passes
  * of the do{}while body (solveLin_BICGStab.C:327-496) and stops early on
- * convergence or failure; kry_fetch_phi copies the current solution back. */
+ * convergence or failure; kry_fetch_phi copies the current solution back: after a
+ * finished solve (converged or out of passes) exactly what kry_solve_* returns --
+ * for constant coefficients that includes the do_BCs the reference's post-loop
+ * residual applies to phi (solveLin_BICGStab.C:512-518, Krylov.C:516) -- and
+ * before that the untreated iterate. */
 int kry_load_const(kry_handle h, const double *phi, const double *rhs, const double *lambda,
                    double Dxx, double Dyy, double Dzz);
 int kry_load_var(kry_handle h, const double *phi, const double *rhs, const double *lambda,

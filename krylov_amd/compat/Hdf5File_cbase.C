@@ -293,22 +293,26 @@ bool Hdf5Stream::Write3DMatrix_withMPI_IO(std::string ArrayName, NumMatrix<float
 		geo[q] = mx_local[2 - q] + 1 + 2 * rim;
 		geo[3 + q] = rank_shift[2 - q];
 	}
+	// A process whose field does not have the extents it announces still takes part in every
+	// collective step: it announces a block of -1 (nothing is sent for it) and all return false together.
+	const long count = (long)geo[0] * geo[1] * geo[2];
+	const bool fits = (long)data.size() == count;
+	if (!fits) {
+		std::cerr << " Write3DMatrix_withMPI_IO: the field's extents do not match mx_local and its rim" << std::endl;
+		geo[0] = -1;
+	}
 	std::vector<int> all(on_disk() ? 6 * comm_size : 0);
 	MPI_Gather(geo, 6, MPI_INT, all.data(), 6, MPI_INT, 0, comm);
-	const long count = (long)geo[0] * geo[1] * geo[2];
-	if ((long)data.size() != count) {
-		std::cerr << " Write3DMatrix_withMPI_IO: the field's extents do not match mx_local and its rim" << std::endl;
-		return false;
-	}
-	bool ok = true;
+	bool ok = fits;
 	if (!on_disk()) {
-		MPI_Send(data.data(), (int)count, MPI_FLOAT, 0, 4711, comm);
+		if (fits) MPI_Send(data.data(), (int)count, MPI_FLOAT, 0, 4711, comm);
 	} else {
 		hsize_t dims[3];
 		for (int q = 0; q < 3; ++q) dims[q] = (hsize_t)(mx_global[2 - q] + 1 + 2 * rim);
 		Type t(le_type(H5T_NATIVE_FLOAT));
 		Space file_space(H5Screate_simple(3, dims, NULL));
-		Dset ds(H5Dcreate2(group, ArrayName.c_str(), t, file_space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));
+		for (int r = 0; r < comm_size; ++r) ok = ok && all[6 * r] >= 0;   // no dataset unless every block is valid
+		Dset ds(ok ? H5Dcreate2(group, ArrayName.c_str(), t, file_space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT) : -1);
 		if (ds < 0) ok = false;
 		if (ok && with_opendxinfo) {
 			float origin[3], delta[3];
@@ -318,6 +322,7 @@ bool Hdf5Stream::Write3DMatrix_withMPI_IO(std::string ArrayName, NumMatrix<float
 		std::vector<float> buf;
 		for (int r = 0; r < comm_size; ++r) {
 			const int *g = &all[6 * r];
+			if (g[0] < 0) continue;                  // that process holds no valid block and sends none
 			const long n = (long)g[0] * g[1] * g[2];
 			const float *src = data.data();
 			if (r != 0) {

@@ -36,6 +36,14 @@ int main(int argc, char **argv)
 		if (!out.AddGlobalAttr("time", 0.25)) ++bad;                       // every process may make every call
 		if (!out.Write3DMatrix_withMPI_IO("rho", f, mxg, mxl, shift, xb, dx)) ++bad;
 		if (!out.Write3DMatrix_withMPI_IO("rho2", f, mxg, mxl, shift, xb, dx, false)) ++bad;
+		// one process announces extents its field does not have: every process gets `false`, none waits for another
+		{
+			int wsize;
+			MPI_Comm_size(MPI_COMM_WORLD, &wsize);
+			NumArray<int> mxw(3);
+			for (int d = 0; d < 3; ++d) mxw[d] = mxl[d] + ((wrank == wsize - 1 && d == 0) ? 1 : 0);
+			if (out.Write3DMatrix_withMPI_IO("rho3", f, mxg, mxw, shift, xb, dx)) ++bad;
+		}
 		out.close();
 	}
 	MPI_Barrier(MPI_COMM_WORLD);

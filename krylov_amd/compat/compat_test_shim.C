@@ -130,6 +130,34 @@ int compat_time_steps(const int mx[3], int L, double eps, int steps, int keep, c
 	return 0;
 }
 
+// Two solves through one BICGStab object with the coefficients kept on the device, the face types
+// changing in between (bc_a, then bc_b) and every array the same: the second solve runs on a new device
+// handle and must stage everything again.  phi_b / staged[1]: what the second solve returned / staged.
+int compat_keep_across_face_change(const int mx[3], int L, double eps, const int bc_a[6], const int bc_b[6],
+                                   const double *phi0, double *phi_b, const double *rhs, const double *lam,
+                                   const double *Dxx, const double *Dyy, const double *Dzz, int staged[2])
+{
+	grid_1D gx(0, 1, mx[0] + 1, 2, 0, true), gy(0, 1, mx[1] + 1, 2, 0, true), gz(0, 1, mx[2] + 1, 2, 0, true);
+	NumMatrix<double, 3> mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy;
+	wrap(mphi, mx, phi0); wrap(mrhs, mx, rhs); wrap(mlam, mx, lam);
+	wrap(mDxx, mx, Dxx); wrap(mDyy, mx, Dyy); wrap(mDzz, mx, Dzz); wrap(mDxy, mx, NULL);
+	BICGStab s;
+	s.set_KeepCoefficients(true);
+	Linsolver3D *ls = &s;
+	NumArray<int> pars(1);
+	pars(0) = L;
+	ls->setup(gx, gy, gz, eps, pars, true, false, 0);
+	for (int t = 0; t < 2; ++t) {
+		BoundaryHandler3D b;
+		for (int f = 0; f < 6; ++f) b.set_bcType(f, t == 0 ? bc_a[f] : bc_b[f]);
+		memcpy(mphi.data(), phi0, mphi.size() * sizeof(double));
+		ls->solve(b, mphi, mrhs, mlam, mDxx, mDyy, mDzz, mDxy, 0, false);
+		staged[t] = s.stagedFields();
+	}
+	memcpy(phi_b, mphi.data(), mphi.size() * sizeof(double));
+	return s.iterations();
+}
+
 // the construction style of the reference's OpenCL solver (BiCGStab3D_CL/main.cpp:410-412, 532-540):
 // constant-coefficient solve on Dirichlet faces; out = {iterations, steptimeMin, steptimeMax, number of step times,
 // sum of the unrounded step times in ms}

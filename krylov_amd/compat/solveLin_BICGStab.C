@@ -60,6 +60,10 @@ void BICGStab::release()
 {
 	if (handle) kry_destroy(handle);
 	handle = NULL;
+	// nothing is resident on a handle that does not exist: the next solve stages every field
+	// (a handle created afterwards may sit at the very address this one had)
+	last_mode = -1;
+	for (int k = 0; k < 5; ++k) last_coef[k] = NULL;
 }
 
 #ifdef parallel
@@ -299,19 +303,18 @@ void BICGStab::solve_int(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, N
                          NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug_)
 {
 	// BICGStab3D/solveLin_BICGStab.C:250-527 runs on the device
-	kry_solver *before = handle;
-	ensure_handle(bounds, phi);
+	ensure_handle(bounds, phi);      // (a new handle forgets what was resident: release())
 	int st;
 	const double *dxy = (use_spatialDiffusion && use_offDiagDiffusion && Dxy.size() > 0) ? Dxy.data() : NULL;
 	const int mode = use_spatialDiffusion ? (dxy ? 2 : 1) : 0;
 	const void *coef[5] = {lambda.data(), use_spatialDiffusion ? Dxx.data() : NULL, use_spatialDiffusion ? Dyy.data() : NULL,
 	                       use_spatialDiffusion ? Dzz.data() : NULL, dxy};
-	bool same = keep_coefficients && handle == before && before != NULL && mode == last_mode;
+	bool same = keep_coefficients && last_mode >= 0 && mode == last_mode;
 	for (int k = 0; k < 5; ++k) same = same && coef[k] == last_coef[k];
 	if (mode == 0) for (int k = 0; k < 3; ++k) same = same && DiffDiag[k] == last_diag[k];
 	for (int k = 0; k < 5; ++k) last_coef[k] = coef[k];
 	for (int k = 0; k < 3; ++k) last_diag[k] = DiffDiag[k];
-	last_mode = mode;
+	last_mode = keep_coefficients ? mode : -1;   // arrays may change freely while the switch is off
 	if (same) {
 		// the operator is on the device already: stage phi and rhs, re-run the prologue, solve
 		st = kry_update_phi(handle, phi.data());

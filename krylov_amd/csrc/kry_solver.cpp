@@ -129,6 +129,7 @@ struct kry_solver {
 	int it_base = 0;           // outer iterations completed (mirrors S->iter)
 	int status = 0;
 	bool done = false;
+	bool tail_bc_done = false;  // the post-loop do_BCs(phi) of a constant-coefficient solve has been applied
 	double norm_rhs = 0, norm_init = 0, norm_final = 0;
 	double solve_ms = 0, stage_ms = 0;
 	double pending_stage_ms = 0;   // staging done by kry_update_* since the last solve
@@ -1160,6 +1161,7 @@ int prologue(kry_solver *h)
 	h->it_base = 0;
 	h->status = 0;
 	h->done = false;
+	h->tail_bc_done = false;
 	h->hist.clear();
 	h->step_ms.clear();
 	h->g_rho0 = 1.; h->g_alpha = 0.; h->g_omega = 1.;
@@ -1900,6 +1902,19 @@ int kry_load_var(kry_handle h, const double *phi, const double *rhs, const doubl
 
 static int solve_tail(kry_handle h, double *phi, int debug);
 
+// After its loop the reference recomputes the true residual (solveLin_BICGStab.C:512-518); the
+// value is unused, but the constant-coefficient operator passes its input -- phi -- through
+// do_BCs (Krylov.C:516): the caller's phi comes back with its boundary cells re-extrapolated.
+// Applied once per finished solve, by whichever call hands phi back first.
+static int finish_phi_bcs(kry_handle h)
+{
+	const bool finished = h->done && (h->status == KRY_OK || h->status == KRY_MAX_ITER);
+	if (h->var || !finished || h->it_base <= 0 || h->tail_bc_done) return 0;
+	CHK(g_do_bcs(h, &Slab::phi));
+	h->tail_bc_done = true;
+	return 0;
+}
+
 // ---- resident re-solves: the coefficients stay on the device -------------------
 
 static int update_field(kry_handle h, const char *who, Field Slab::*f, const double *src, bool exchange)
@@ -1967,6 +1982,7 @@ int kry_fetch_phi(kry_handle h, double *phi)
 {
 	if (!h || !phi) return KRY_ERR_ARG;
 	if (!h->loaded) { set_err("no problem loaded"); return KRY_ERR_STATE; }
+	CHK(finish_phi_bcs(h));      // a finished solve hands back what kry_solve_* would; an unfinished one the iterate
 	return finish_solve(h, phi);
 }
 
@@ -1981,10 +1997,7 @@ static int solve_tail(kry_handle h, double *phi, int debug)
 		printf(" Norm: %g %g %g %g %d\n", h->norm_final, h->norm_final / h->norm_rhs, h->norm_rhs,
 		       h->d.eps * h->norm_rhs, h->it_base);
 	}
-	// After its loop the reference recomputes the true residual (solveLin_BICGStab.C:512-518); the
-	// value is unused, but the constant-coefficient operator passes its input -- phi -- through
-	// do_BCs (Krylov.C:516): the caller's phi comes back with its boundary cells re-extrapolated.
-	if (!h->var && h->it_base > 0 && (st == KRY_OK || st == KRY_MAX_ITER)) CHK(g_do_bcs(h, &Slab::phi));
+	CHK(finish_phi_bcs(h));
 	int st2 = finish_solve(h, phi);
 	return st2 < 0 ? st2 : st;
 }
