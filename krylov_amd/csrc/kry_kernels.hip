@@ -982,6 +982,22 @@ __device__ inline void plane_weights(const KryGeo &g, long q, double (&wxy)[2], 
 	}
 }
 
+// Which of a thread's double2 elements of a plane segment are worth touching.  General
+// boundaries: every stored cell of the plane (ghost cells are live data).  Dirichlet faces:
+// the vectors are zero on the faces and behind them and stay so under every update, and
+// phi + c*0 is phi, so only pairs holding an interior point (rows 1..my-1, columns 0..mx-1)
+// are loaded, updated and stored: the skipped pairs contributed +0 to every sum, the sums
+// keep their bits, and the row padding, ghost rows and face columns cost no memory traffic.
+template <bool GEN>
+__device__ inline bool seg_live(const KryGeo &g, long q)
+{
+	if (GEN) return q < g.ps;
+	const long qq = q + QOFF;
+	const int row = (int)(qq / g.px);
+	const int i = (int)(qq - (long)row * g.px) - 2, j = row - 1;
+	return j >= 1 && j <= g.my - 1 && i >= 0 && i <= g.mx - 1;
+}
+
 template <bool GEN>
 __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 {
@@ -1000,21 +1016,25 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 			plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], c);
 		}
 	}
+	bool live[UN];
+#pragma unroll
+	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
-		// all loads first (reads past the end of a plane stay inside the allocation)
+		// all loads first
 		double2 r2[UN], r1[UN], r0[UN], u1[UN];
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long p = pb + q0 + 2L * i * NT;
-			r2[i] = ld2s(a.v[2] + p); r1[i] = ld2s(a.v[1] + p); r0[i] = ld2s(a.v[0] + p); u1[i] = ld2s(a.v[3] + p);
+			if (live[i]) {
+				r2[i] = ld2s(a.v[2] + p); r1[i] = ld2s(a.v[1] + p); r0[i] = ld2s(a.v[0] + p); u1[i] = ld2s(a.v[3] + p);
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
-			const long q = q0 + 2L * i * NT;
-			if (q < a.g.ps) {
+			if (live[i]) {
 				r2[i] = axpy2(r2[i], r1[i], ntau);   // kept in registers only: k_final recomputes it
 				r0[i] = axpy2(r0[i], u1[i], nalpha);  // r0'' = r0' - alpha*u1, likewise
 				if (GEN) {
@@ -1069,26 +1089,31 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 #pragma unroll
 		for (int i = 0; i < UN; ++i) plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], wcorner[GEN ? i : 0]);
 	}
+	bool live[UN];
+#pragma unroll
+	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
 		double2 r[UN][L + 1], u0[UN], ph[UN], rt[UN], u1[L == 2 ? UN : 1], u2[L == 2 ? UN : 1];
-		// all loads first (reads past the end of a plane stay inside the allocation)
+		// all loads first
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long p = pb + q0 + 2L * i * NT;
+			if (live[i]) {
 #pragma unroll
-			for (int j = 0; j <= L; ++j) r[i][j] = ld2s(a.v[j] + p);
-			u0[i] = ld2s(a.v[L + 1] + p);
-			ph[i] = ld2s(a.w[0] + p);
-			rt[i] = ld2s(a.v[L + 2] + p);
-			if (L == 2) { u1[L == 2 ? i : 0] = ld2s(a.v[L + 3] + p); u2[L == 2 ? i : 0] = ld2s(a.v[L + 4] + p); }
+				for (int j = 0; j <= L; ++j) r[i][j] = ld2s(a.v[j] + p);
+				u0[i] = ld2s(a.v[L + 1] + p);
+				ph[i] = ld2s(a.w[0] + p);
+				rt[i] = ld2s(a.v[L + 2] + p);
+				if (L == 2) { u1[L == 2 ? i : 0] = ld2s(a.v[L + 3] + p); u2[L == 2 ? i : 0] = ld2s(a.v[L + 4] + p); }
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long q = q0 + 2L * i * NT;
-			if (q < a.g.ps) {
+			if (live[i]) {
 				const long p = pb + q;
 				if (L == 2) r[i][2] = axpy2(r[i][2], r[i][1], ntau12);   // the Gram-Schmidt step of k_mgs2
 				double2 phv = ph[i];
@@ -1159,6 +1184,9 @@ __global__ __launch_bounds__(NT) void k_bicgn(const KryStream a, const KryPointN
 	const int jj = f.jj;
 	const double nbeta = -S->beta, nalpha = -S->alpha, aprev = S->alpha0;
 	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	bool live[UN];
+#pragma unroll
+	for (int i = 0; i < UN; ++i) live[i] = a.gen ? seg_live<true>(a.g, q0 + 2L * i * NT) : seg_live<false>(a.g, q0 + 2L * i * NT);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const long pb = (long)(a.zfirst + pl + 1) * a.g.ps + QOFF;
 		double2 un[UN], ro[UN];
@@ -1167,16 +1195,18 @@ __global__ __launch_bounds__(NT) void k_bicgn(const KryStream a, const KryPointN
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long p = pb + q0 + 2L * i * NT;
-				ph[i] = ld2s(a.w[0] + p);
-				uo[i] = ld2s(f.u[0] + p);
-				ro[i] = ld2s(f.r[0] + p);
+				if (live[i]) {
+					ph[i] = ld2s(a.w[0] + p);
+					uo[i] = ld2s(f.u[0] + p);
+					ro[i] = ld2s(f.r[0] + p);
+				}
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long q = q0 + 2L * i * NT;
 				ph[i] = axpy2(ph[i], uo[i], aprev);
 				un[i] = axpy2(ro[i], uo[i], nbeta);
-				if (q < a.g.ps) st2s(a.w[0] + pb + q, ph[i]);
+				if (live[i]) st2s(a.w[0] + pb + q, ph[i]);
 			}
 		}
 		for (int ii = 0; ii < jj; ++ii) {
@@ -1185,15 +1215,17 @@ __global__ __launch_bounds__(NT) void k_bicgn(const KryStream a, const KryPointN
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long p = pb + q0 + 2L * i * NT;
-				nx[i] = ld2s(f.u[ii + 1] + p);
-				if (more) rn[i] = ld2s(f.r[ii + 1] + p);
+				if (live[i]) {
+					nx[i] = ld2s(f.u[ii + 1] + p);
+					if (more) rn[i] = ld2s(f.r[ii + 1] + p);
+				}
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long q = q0 + 2L * i * NT;
 				if (more) nx[i] = axpy2(rn[i], nx[i], nbeta);          // the updated u_(ii+1)
 				const double2 rnew = axpy2(ro[i], nx[i], nalpha);
-				if (q < a.g.ps) {
+				if (live[i]) {
 					st2s(f.u[ii] + pb + q, un[i]);
 					st2s(f.r[ii] + pb + q, rnew);
 				}
@@ -1225,6 +1257,9 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 			plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], c);
 		}
 	}
+	bool live[UN];
+#pragma unroll
+	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
@@ -1233,14 +1268,16 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long p = pb + q0 + 2L * i * NT;
-			rj[i] = ld2s(a.v[0] + p);
-			if (iip > 0) rp[i] = ld2s(a.v[1] + p);
-			rk[i] = ld2s(a.v[2] + p);
+			if (live[i]) {
+				rj[i] = ld2s(a.v[0] + p);
+				if (iip > 0) rp[i] = ld2s(a.v[1] + p);
+				rk[i] = ld2s(a.v[2] + p);
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long q = q0 + 2L * i * NT;
-			if (q < a.g.ps) {
+			if (live[i]) {
 				if (iip > 0) {
 					rj[i] = axpy2(rj[i], rp[i], ntau);
 					st2s(a.w[0] + pb + q, rj[i]);
@@ -1292,6 +1329,9 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 #pragma unroll
 		for (int i = 0; i < UN; ++i) plane_weights(a.g, q0 + 2L * i * NT, wxy[GEN ? i : 0], wcorner[GEN ? i : 0]);
 	}
+	bool live[UN];
+#pragma unroll
+	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
 	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
@@ -1303,12 +1343,14 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long p = pb + q0 + 2L * i * NT;
-				ph[i] = ld2s(a.w[0] + p);
-				r0[i] = ld2s(f.r[0] + p);
-				u0[i] = ld2s(f.u[0] + p);
-				rt[i] = ld2s(a.v[0] + p);
-				rl[i] = ld2s(f.r[L] + p);
-				ul[i] = ld2s(f.u[L] + p);
+				if (live[i]) {
+					ph[i] = ld2s(a.w[0] + p);
+					r0[i] = ld2s(f.r[0] + p);
+					u0[i] = ld2s(f.u[0] + p);
+					rt[i] = ld2s(a.v[0] + p);
+					rl[i] = ld2s(f.r[L] + p);
+					ul[i] = ld2s(f.u[L] + p);
+				}
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
@@ -1324,8 +1366,10 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
 				const long p = pb + q0 + 2L * i * NT;
-				rj[i] = ld2s(f.r[j] + p);
-				uj[i] = ld2s(f.u[j] + p);
+				if (live[i]) {
+					rj[i] = ld2s(f.r[j] + p);
+					uj[i] = ld2s(f.u[j] + p);
+				}
 			}
 #pragma unroll
 			for (int i = 0; i < UN; ++i) {
@@ -1337,7 +1381,7 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 #pragma unroll
 		for (int i = 0; i < UN; ++i) {
 			const long q = q0 + 2L * i * NT;
-			if (q < a.g.ps) {
+			if (live[i]) {
 				const long p = pb + q;
 				st2s(a.w[0] + p, ph[i]);
 				st2s(f.r0 + p, r0[i]);
