@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #define NT 256                 // threads per block in every kernel here
 #define NW (NT / 64)           // wavefronts per block
@@ -603,6 +604,10 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int ccol = cside ? c0 + TXW + (cside - 1) : c0 - 1;
 	const long coff = (long)(y0 + crr - 1 + 1) * g.px + ccol;
 	const int cl = crr * LW + (cside ? 130 : 1);
+	// Dirichlet faces: the solver's work vectors are zero on and behind a face, so a halo column on or
+	// behind an x face of the domain (which sits in a cache line nothing else reads) is not loaded.
+	// (Not so for the residual and plain operator kinds: their input is the caller's array.)
+	const bool cload = hcol && (GEN || !UPD || !((cside == 0 && tx == 0) || (cside == 1 && ccol - 2 >= g.mx)));
 	// halo-column cells that are ghost / face cells of this tile's rows: updated here
 	// (behind a Dirichlet face of the domain these cells are zero and stay zero under every update)
 	const bool cstore = GEN && hcol && crr >= 1 && crr <= TY && (y0 + crr - 1) <= g.my + 1 &&
@@ -637,7 +642,11 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	// issue the loads that psi of plane z needs (own points and halo ring)
 	auto issue = [&](int z) {
 		zi = z;
+#ifdef KRY_EXP_CLAMPZ
+		const long pb = plane(min(max(z, z0), z1 - 1));   // timing experiment only (wrong results): no chunk halo planes from memory
+#else
 		const long pb = plane(z);
+#endif
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			nx[e] = ld2(a.X + pb + off[e]);
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			if (DEFER && nz >= 1) hz1 = ld2(a.Z1 + pb + hoff);
 			if (DEFER && nz >= 2) hz2 = ld2(a.Z2 + pb + hoff);
 		}
-		if (hcol) {
+		if (cload) {
 			sx = a.X[pb + coff];
 			if (UPD) sy = a.Y[pb + coff];
 			if (DEFER && nz >= 1) sz1 = a.Z1[pb + coff];
@@ -1705,11 +1714,41 @@ __global__ __launch_bounds__(NT) void g_wdot(KryGeo g, const double *x, const do
 // ---------------------------------------------------------------------------
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Blocks per compute unit.  A compute unit that is left with ONE block of a fused kernel (4 waves) draws
+// about three quarters of its share of the memory bandwidth; with two or more it draws all of it.  Grids
+// are therefore sized in multiples of 2 x the number of compute units (choose_chunk_depth), which leaves
+// no such tail for kernels that fit 2 or 4 blocks on a compute unit.  A kernel whose registers allow 3
+// would run 1024 blocks as 3 + 1 per compute unit: it is held to 2 by asking for dynamic LDS it does not
+// use (constant coefficients, 256^3: 0.191 -> 0.177 ms).  KRY_LDS_PAD=bytes overrides (tuning).
+#define KRY_LDS_PER_CU (160 * 1024)
+template <void (*KERN)(const KryFused)>
+static int fused_pad()
+{
+	static int pad = -1;     // one per kernel instantiation; all GPUs of a process are alike
+	if (pad < 0) {
+		const char *e = getenv("KRY_LDS_PAD");
+		int n = 0, p = 0;
+		if (e) p = std::max(0, atoi(e));
+		else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERN, NT, 0) == hipSuccess && n == 3) {
+			hipFuncAttributes fa;
+			if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(KERN)) == hipSuccess) {
+				// two blocks fit, three do not: a little over a third of the LDS per block
+				const int want = KRY_LDS_PER_CU / 3 + 2048;
+				p = std::max(0, want - (int)fa.sharedSizeBytes);
+			}
+		}
+		(void)hipGetLastError();
+		pad = p;
+	}
+	return pad;
+}
+
 template <int KIND, int TY>
 static hipError_t launch_fused_t(const KryFused &a, bool var, bool offd, bool exact, hipStream_t st)
 {
 	dim3 grid(a.nblk), block(NT);
-#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, TY, V, O, E, false>), grid, block, 0, st, a)
+#define KRY_LAUNCH(V, O, E) \
+	hipLaunchKernelGGL((k_fused<KIND, TY, V, O, E, false>), grid, block, (fused_pad<k_fused<KIND, TY, V, O, E, false>>()), st, a)
 	if (!var) KRY_LAUNCH(false, false, true);
 	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
 	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
@@ -1723,8 +1762,11 @@ template <int KIND>
 static hipError_t launch_fused_gen_t(const KryFused &a, bool var, bool offd, bool exact, bool inbc, hipStream_t st)
 {
 	dim3 grid(a.nblk), block(NT);
-#define KRY_LAUNCH(V, O, E) hipLaunchKernelGGL((k_fused<KIND, 8, V, O, E, true>), grid, block, 0, st, a)
-	if (!var && inbc) hipLaunchKernelGGL((k_fused<KIND, 8, false, false, true, true, true>), grid, block, 0, st, a);
+#define KRY_LAUNCH(V, O, E) \
+	hipLaunchKernelGGL((k_fused<KIND, 8, V, O, E, true>), grid, block, (fused_pad<k_fused<KIND, 8, V, O, E, true>>()), st, a)
+	if (!var && inbc)
+		hipLaunchKernelGGL((k_fused<KIND, 8, false, false, true, true, true>), grid, block,
+		                   (fused_pad<k_fused<KIND, 8, false, false, true, true, true>>()), st, a);
 	else if (!var) KRY_LAUNCH(false, false, true);
 	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
 	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
@@ -1777,23 +1819,31 @@ hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool 
 	return hipErrorInvalidValue;
 }
 
-// Blocks of a fused stencil kernel (the B kernel of the first BiCG step stands for all of
-// them) that one compute unit holds at a time; 0 when the runtime cannot tell.
+// Blocks of the fused stencil kernels that one compute unit holds at a time, as they are launched
+// (fused_pad): the smallest over the kernels of a pass; 0 when the runtime cannot tell.
 int kry_fused_blocks_per_cu(int ty, bool var, bool offd, bool exact, bool gen)
 {
-	int n = 0;
-	hipError_t e = hipErrorInvalidValue;
-#define KRY_OCC(T, V, O, E, G) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fused<KF_B0, T, V, O, E, G>, NT, 0)
-#define KRY_OCC_VOE(T, G)                                                                   \
-	if (!var) KRY_OCC(T, false, false, true, G);                                            \
-	else if (!offd) { if (exact) KRY_OCC(T, true, false, true, G); else KRY_OCC(T, true, false, false, G); } \
-	else { if (exact) KRY_OCC(T, true, true, true, G); else KRY_OCC(T, true, true, false, G); }
-	if (gen) { KRY_OCC_VOE(8, true) }
-	else if (ty == 8) { KRY_OCC_VOE(8, false) }
-	else { KRY_OCC_VOE(16, false) }
+	int least = 0;
+	bool ok = true;
+	auto take = [&](auto kern, int pad) {
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, NT, pad) != hipSuccess) { ok = false; return; }
+		least = least ? std::min(least, n) : n;
+	};
+#define KRY_OCC(K, T, V, O, E, G) take(k_fused<K, T, V, O, E, G>, fused_pad<k_fused<K, T, V, O, E, G>>())
+#define KRY_OCC_VOE(K, T, G)                                                                   \
+	if (!var) KRY_OCC(K, T, false, false, true, G);                                            \
+	else if (!offd) { if (exact) KRY_OCC(K, T, true, false, true, G); else KRY_OCC(K, T, true, false, false, G); } \
+	else { if (exact) KRY_OCC(K, T, true, true, true, G); else KRY_OCC(K, T, true, true, false, G); }
+#define KRY_OCC_KINDS(T, G) { KRY_OCC_VOE(KF_A0, T, G) KRY_OCC_VOE(KF_B0, T, G) }
+	if (gen) KRY_OCC_KINDS(8, true)
+	else if (ty == 8) KRY_OCC_KINDS(8, false)
+	else KRY_OCC_KINDS(16, false)
+#undef KRY_OCC_KINDS
 #undef KRY_OCC_VOE
 #undef KRY_OCC
-	return e == hipSuccess ? n : 0;
+	(void)hipGetLastError();
+	return ok ? least : 0;
 }
 
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st)
