@@ -54,8 +54,8 @@ struct KryFused {
 	int ch_sel;              // 0: all chunks, 1: chunk 0 and the last n_edge-1 chunks, 2: the chunks in between
 	int n_edge;              // 2 or 3
 	int blk_off;             // offset of this launch's blocks in the partial-sum array
-	int rev;                 // 1: the blocks take the tiles in reverse order (the B kernels: they start where the A
-	                         // kernel before them ended, on data the memory-side cache still holds)
+	int rev;                 // 1: the blocks take the tiles in reverse order (every kernel starts where the one
+	                         // before it ended, on data the memory-side cache still holds)
 };
 
 // pointwise statements of BiCG step jj > 0 of the general-l pass: the current copies of r_0..r_jj-1 and u_0..u_jj
@@ -75,6 +75,7 @@ struct KryStream {
 	int nplanes;             // planes processed, strided over blockIdx.y
 	int cnt_lo, cnt_hi;      // planes that count in the dot products
 	int gen;                 // 1: general boundaries (weighted dots over the points 0..m)
+	int rev;                 // 1: the blocks take the plane segments in reverse order
 };
 
 hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool offd, bool exact,

@@ -247,10 +247,13 @@ __device__ inline void mail_allreduce(double (*red)[ND], const KryRed &r)
 	}
 }
 
+// slot: where this block's partial sums go.  It names the block's WORK (tile, plane segment), not its
+// place in the launch, so the order in which the partials are added does not depend on the order in
+// which the blocks take the work (-1: the block's own index).
 template <int ND>
-__device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, int blk_off = 0)
+__device__ inline void reduce_and_finalize(double (&acc)[ND], const KryRed &r, long slot = -1)
 {
-	const long bid = blk_off + blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+	const long bid = slot >= 0 ? slot : blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
 	__shared__ double red[NW][ND];
 	__shared__ int is_last;
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	}
 	if (KIND != KF_SPMV) {
 		KryRed r = a.red;
-		reduce_and_finalize<ND>(acc, r, a.blk_off);
+		reduce_and_finalize<ND>(acc, r, a.blk_off + bid);
 	}
 }
 
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(NT) void k_surf(const KryFused a)
 		}
 	}
 	KryRed r = a.red;
-	reduce_and_finalize<ND>(acc, r, a.blk_off);
+	reduce_and_finalize<ND>(acc, r, a.blk_off + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1016,7 +1019,10 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 	const double ntau = -S->tau[1][2];
 	const double nalpha = -S->alpha;
 	double acc[3] = {0., 0., 0.};
-	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	// rev: the blocks take the plane segments in reverse order (the sums do not notice: see reduce_and_finalize)
+	const int bx = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+	const int by = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+	const long q0 = 2 * ((long)bx * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
 	if (GEN) {
 #pragma unroll
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 	bool live[UN];
 #pragma unroll
 	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
-	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+	for (int pl = by; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(NT) void k_mgs2(const KryStream a)
 			}
 		}
 	}
-	reduce_and_finalize<3>(acc, a.red);
+	reduce_and_finalize<3>(acc, a.red, bx + (long)gridDim.x * by);
 }
 
 // End of an outer pass (solveLin_BICGStab.C:403, 450-464):
@@ -1091,7 +1097,10 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 	for (int j = 1; j <= L; ++j) { g1[j] = S->gamma[j]; gp[j] = S->gammap[j]; gpp[j] = (j < L) ? S->gammapp[j] : 0.; }
 	constexpr int UN = SEG2 / NT;
 	double acc[2] = {0., 0.};
-	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	// rev: the blocks take the plane segments in reverse order (the sums do not notice: see reduce_and_finalize)
+	const int bx = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+	const int by = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+	const long q0 = 2 * ((long)bx * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
 	bool wcorner[GEN ? UN : 1][2];
 	if (GEN) {
@@ -1101,7 +1110,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 	bool live[UN];
 #pragma unroll
 	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
-	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+	for (int pl = by; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
@@ -1172,7 +1181,7 @@ __global__ __launch_bounds__(NT) void k_final(const KryStream a)
 			}
 		}
 	}
-	reduce_and_finalize<2>(acc, a.red);
+	reduce_and_finalize<2>(acc, a.red, bx + (long)gridDim.x * by);
 }
 
 // ---------------------------------------------------------------------------
@@ -1192,11 +1201,13 @@ __global__ __launch_bounds__(NT) void k_bicgn(const KryStream a, const KryPointN
 	constexpr int UN = SEG2 / NT;
 	const int jj = f.jj;
 	const double nbeta = -S->beta, nalpha = -S->alpha, aprev = S->alpha0;
-	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	const int bx = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+	const int by = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+	const long q0 = 2 * ((long)bx * SEG2 + threadIdx.x);
 	bool live[UN];
 #pragma unroll
 	for (int i = 0; i < UN; ++i) live[i] = a.gen ? seg_live<true>(a.g, q0 + 2L * i * NT) : seg_live<false>(a.g, q0 + 2L * i * NT);
-	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+	for (int pl = by; pl < a.nplanes; pl += gridDim.y) {
 		const long pb = (long)(a.zfirst + pl + 1) * a.g.ps + QOFF;
 		double2 un[UN], ro[UN];
 		{
@@ -1257,7 +1268,10 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 	constexpr int UN = SEG2 / NT;
 	const double ntau = iip > 0 ? -S->tau[iip][jj] : 0.;
 	double acc[2] = {0., 0.};
-	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	// rev: the blocks take the plane segments in reverse order (the sums do not notice: see reduce_and_finalize)
+	const int bx = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+	const int by = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+	const long q0 = 2 * ((long)bx * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
 	if (GEN) {
 #pragma unroll
@@ -1269,7 +1283,7 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 	bool live[UN];
 #pragma unroll
 	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
-	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+	for (int pl = by; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
@@ -1316,7 +1330,7 @@ __global__ __launch_bounds__(NT) void k_mgsn(const KryStream a, int jj, int iip,
 			}
 		}
 	}
-	reduce_and_finalize<2>(acc, a.red);
+	reduce_and_finalize<2>(acc, a.red, bx + (long)gridDim.x * by);
 }
 
 // End of an outer pass for any l (solveLin_BICGStab.C:450-464), statement by statement:
@@ -1331,7 +1345,10 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 	constexpr int UN = SEG2 / NT;
 	const int L = f.L;
 	double acc[2] = {0., 0.};
-	const long q0 = 2 * ((long)blockIdx.x * SEG2 + threadIdx.x);
+	// rev: the blocks take the plane segments in reverse order (the sums do not notice: see reduce_and_finalize)
+	const int bx = a.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+	const int by = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+	const long q0 = 2 * ((long)bx * SEG2 + threadIdx.x);
 	double wxy[GEN ? UN : 1][2];
 	bool wcorner[GEN ? UN : 1][2];
 	if (GEN) {
@@ -1341,7 +1358,7 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 	bool live[UN];
 #pragma unroll
 	for (int i = 0; i < UN; ++i) live[i] = seg_live<GEN>(a.g, q0 + 2L * i * NT);
-	for (int pl = blockIdx.y; pl < a.nplanes; pl += gridDim.y) {
+	for (int pl = by; pl < a.nplanes; pl += gridDim.y) {
 		const int z = a.zfirst + pl;
 		const bool cnt = (z >= a.cnt_lo && z <= a.cnt_hi);
 		const long pb = (long)(z + 1) * a.g.ps + QOFF;
@@ -1412,7 +1429,7 @@ __global__ __launch_bounds__(NT) void k_finaln(const KryStream a, const KryFinal
 			}
 		}
 	}
-	reduce_and_finalize<2>(acc, a.red);
+	reduce_and_finalize<2>(acc, a.red, bx + (long)gridDim.x * by);
 }
 
 // ---------------------------------------------------------------------------

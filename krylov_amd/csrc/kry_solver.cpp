@@ -129,6 +129,7 @@ struct kry_solver {
 	int it_base = 0;           // outer iterations completed (mirrors S->iter)
 	int status = 0;
 	bool done = false;
+	bool alt = true;            // every kernel of a pass takes its work in the opposite order of the one before it
 	bool tail_bc_done = false;  // the post-loop do_BCs(phi) of a constant-coefficient solve has been applied
 	double norm_rhs = 0, norm_init = 0, norm_final = 0;
 	double solve_ms = 0, stage_ms = 0;
@@ -803,6 +804,11 @@ int fused_pass(kry_solver *h, int it)
 	if (h->L > 2) return fused_pass_general(h, it);
 	const int p = it & 1, q = 1 - p;
 	const int L = h->L;
+	// Order of the work inside a launch: every kernel starts where the one before it ended (the
+	// memory-side cache still holds the end of its data), so the kernels of the run alternate
+	// between ascending and descending order.  k: place of the kernel in the pass.
+	const int nk = (L == 1) ? 3 : 6;
+	auto rev_of = [&](int k, bool b_kernel) { return h->alt ? ((it * nk + k) & 1) : (b_kernel ? 1 : 0); };
 	auto for_slabs = [&](auto &&fn) -> int {
 		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
 		return 0;
@@ -815,6 +821,7 @@ int fused_pass(kry_solver *h, int it)
 	// --- jj = 0, A: u0 -= gamma_L*u_L [- gamma_1*u_1] (previous pass) ; u0 = r0 - beta*u0 ; u1 = A u0 ; (u1, r~)
 	CHK(stencil_step(h, KF_A0, [&](Slab &s) {
 		KryFused a = fused_base(h, s, PH_A);
+		a.rev = rev_of(0, false);
 		a.X = s.rb[0][p].p; a.Y = s.ub[0][p].p; a.Xout = s.ub[0][q].p;
 		if (L == 1) { a.nz = 1; a.Z1 = s.ub[1][p].p; a.O = s.ub[1][q].p; }
 		else { a.nz = 0; a.O = s.ub[1][p].p; }
@@ -826,7 +833,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- B (last): r0 -= alpha*u1 ; r1 = A r0 ; (r0,r1), (r1,r1)
 		CHK(stencil_step(h, KF_B0L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL1);
-			a.rev = 1;
+			a.rev = rev_of(1, true);
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][q].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][0].p;
 			return a;
@@ -836,7 +843,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 0, B: r0 -= alpha*u1 ; r1 = A r0 ; (r1, r~)
 		CHK(stencil_step(h, KF_B0, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_B);
-			a.rev = 1;
+			a.rev = rev_of(1, true);
 			a.X = s.rb[0][p].p; a.Y = s.ub[1][p].p; a.Xout = s.rb[0][q].p;
 			a.O = s.rb[1][p].p;
 			return a;
@@ -845,6 +852,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 1, A: u1 = r1 - beta*u1 ; u2 = A u1 ; (u2, r~)
 		CHK(stencil_step(h, KF_A1, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_A);
+			a.rev = rev_of(2, false);
 			a.X = s.rb[1][p].p; a.Y = s.ub[1][p].p; a.Xout = s.ub[1][q].p;
 			a.O = s.ub[2][0].p;
 			return a;
@@ -853,7 +861,7 @@ int fused_pass(kry_solver *h, int it)
 		// --- jj = 1, B (last): r1 -= alpha*u2 ; r2 = A r1 ; (r1,r1), (r2,r1)
 		CHK(stencil_step(h, KF_B1L, [&](Slab &s) {
 			KryFused a = fused_base(h, s, PH_BL2);
-			a.rev = 1;
+			a.rev = rev_of(3, true);
 			a.X = s.rb[1][p].p; a.Y = s.ub[2][0].p; a.Xout = s.rb[1][q].p;
 			a.O = s.rb[2][0].p;
 			return a;
@@ -863,6 +871,7 @@ int fused_pass(kry_solver *h, int it)
 		CHK(for_slabs([&](Slab &s, int) -> int {
 			int nbx, nby;
 			KryStream a = stream_base(h, s, PH_M2, &nbx, &nby, 4);
+			a.rev = rev_of(4, false);
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][q].p; a.v[2] = s.rb[2][0].p; a.v[3] = s.ub[1][q].p;
 			a.w[0] = s.rb[2][0].p;
 			HIPCHK(hipSetDevice(s.device));
@@ -878,6 +887,7 @@ int fused_pass(kry_solver *h, int it)
 	CHK(for_slabs([&](Slab &s, int) -> int {
 		int nbx, nby;
 		KryStream a = stream_base(h, s, PH_F, &nbx, &nby, 1);
+		a.rev = rev_of(nk - 1, false);
 		if (L == 1) {
 			a.v[0] = s.rb[0][q].p; a.v[1] = s.rb[1][0].p;
 			a.v[2] = s.ub[0][q].p;
@@ -1572,6 +1582,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 	if (const char *e = getenv("KRY_OVERLAP")) h->overlap = atoi(e) != 0;
 	if (const char *e = getenv("KRY_PROFILE")) h->profile = atoi(e) != 0;
 	if (const char *e = getenv("KRY_GRAPH")) h->use_graph = atoi(e) != 0;
+	if (const char *e = getenv("KRY_ALT")) h->alt = atoi(e) != 0;
 	if (d->flags & KRY_NO_GRAPH) h->use_graph = false;
 	h->slabs.resize(d->slab_count);
 	int st = 0;

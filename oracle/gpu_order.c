@@ -84,11 +84,13 @@ static double grid_total(const double *partial, long nblk)
 	return block_total(tot);
 }
 
-/* block index of a launch of nb blocks -> tile index (the XCD-aware map of k_fused) */
+/* A block's partial sums are stored under the index of the TILE it worked on, not under its place in
+ * the launch: the order in which the blocks take the tiles (XCD-aware, ascending or descending) does not
+ * enter the sums.  Position in the partial array -> tile index: the identity. */
 static long swizzle(long bp, long nb)
 {
-	const long q = nb >> 3, r = nb & 7, x = bp & 7;
-	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bp >> 3);
+	(void)nb;
+	return bp;
 }
 
 /* fused stencil kernels: k_fused, on one slab */
@@ -102,7 +104,6 @@ static int fused_geometry(const orc_cfg *c, zslab sl, int *nchunk, int *n_edge)
 	return *nchunk > *n_edge;
 }
 
-static int g_rev = 0;           /* 1 while the sum of a B kernel is formed: its blocks take the tiles in reverse order */
 
 static double fused_sum_slab(const orc_cfg *c, const double *A, const double *B, zslab sl, int split)
 {
@@ -120,16 +121,13 @@ static double fused_sum_slab(const orc_cfg *c, const double *A, const double *B,
 		int ch;
 		if (!split) {
 			bid = swizzle(pi, nblk);
-			if (g_rev) bid = nblk - 1 - bid;
 			ch = (int)(bid / tiles);
 		} else if (pi < n_edge * tiles) {
 			bid = swizzle(pi, n_edge * tiles);
-			if (g_rev) bid = n_edge * tiles - 1 - bid;
 			ch = (int)(bid / tiles);
 			ch = ch ? nchunk - n_edge + ch : 0;
 		} else {
 			bid = swizzle(pi - n_edge * tiles, (nchunk - n_edge) * tiles);
-			if (g_rev) bid = (nchunk - n_edge) * tiles - 1 - bid;
 			ch = (int)(bid / tiles) + 1;
 		}
 		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty);
@@ -254,7 +252,7 @@ static double fused_gen_sum_slab(const orc_cfg *c, const double *A, const double
 	if (ns < 1) ns = 1;
 	double *partial = (double *)malloc((size_t)(nf + ns) * sizeof(double));
 	for (long bp = 0; bp < nf; ++bp) {
-		const long bid = g_rev ? nf - 1 - swizzle(bp, nf) : swizzle(bp, nf);
+		const long bid = swizzle(bp, nf);
 		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
 		const int z0 = zlo + ch * zc;
 		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
@@ -411,20 +409,7 @@ static double wdot_sum(const orc_cfg *c, const double *A, const double *B, int n
 	return v;
 }
 
-static double hook_fwd(void *ctx, int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b);
-
 static double hook(void *ctx, int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b)
-{
-	/* sums formed by a B kernel (r_jj+1 = A r_jj): rho of jj > 0, and the dots of the last B kernel for l <= 2 */
-	const int b_kernel = (site == ORC_SITE_RHO && jj > 0) ||
-	                     (c->L <= 2 && (site == ORC_SITE_TAU || ((site == ORC_SITE_SIGMA || site == ORC_SITE_GAMMAP) && jj == 1)));
-	g_rev = b_kernel;
-	const double v = hook_fwd(ctx, site, iter, jj, c, a, b);
-	g_rev = 0;
-	return v;
-}
-
-static double hook_fwd(void *ctx, int site, int iter, int jj, const orc_cfg *c, const double *a, const double *b)
 {
 	(void)ctx;
 	/* l > 2: every dot of the Gram-Schmidt part has a streaming kernel of its own (k_mgsn) */
