@@ -657,13 +657,21 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			if (DEFER && nz >= 1) nz1[DEFER ? e : 0] = ld2(a.Z1 + pb + off[e]);
 			if (DEFER && nz >= 2) nz2[DEFER ? e : 0] = ld2(a.Z2 + pb + off[e]);
 		}
+#ifdef KRY_EXP_NOHROW
+		if (false) {                             // timing experiment only (wrong results)
+#else
 		if (hrow) {
+#endif
 			hx = ld2(a.X + pb + hoff);
 			if (UPD) hy = ld2(a.Y + pb + hoff);
 			if (DEFER && nz >= 1) hz1 = ld2(a.Z1 + pb + hoff);
 			if (DEFER && nz >= 2) hz2 = ld2(a.Z2 + pb + hoff);
 		}
+#ifdef KRY_EXP_NOHCOL
+		if (false) {                             // timing experiment only (wrong results)
+#else
 		if (cload) {
+#endif
 			sx = a.X[pb + coff];
 			if (UPD) sy = a.Y[pb + coff];
 			if (DEFER && nz >= 1) sz1 = a.Z1[pb + coff];
@@ -750,6 +758,22 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	to_lds(pc, lds[z0 & 1]);
 	store_psi(pc, z0);
 	issue(z0 + 1);
+	// one-pass operands of the stencil (lambda, r~) are fetched one plane ahead as well: nothing the
+	// stencil of a plane waits for is requested in the same step (256^3 constant coefficients: -2.5 %)
+	// (not where the registers for it would cost a resident block or spill: the instantiations with
+	// Dxy and the general-boundary ones with field coefficients fetch them in the step itself)
+	constexpr bool HAS_RT = (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0);
+	constexpr bool PFC = !OFFD && !(GEN && VAR);
+	double2 lamn[VD], rtn[HAS_RT ? VD : 1];
+	auto issue_coef = [&](int z) {
+		const long pbn = plane(z);
+#pragma unroll
+		for (int e = 0; e < VD; ++e) {
+			lamn[e] = ld2s(a.lam + pbn + off[e]);
+			if (HAS_RT) rtn[HAS_RT ? e : 0] = ld2s(a.RT + pbn + off[e]);
+		}
+	};
+	if (PFC) issue_coef(z0);
 	__syncthreads();
 
 	for (int z = z0; z < z1; ++z) {
@@ -766,12 +790,21 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		// plane 0 is a domain face or counted by the lower slab; with general
 		// boundaries the face plane mz is left to k_surf as well
 		const bool cnt = (z >= 1) && (!GEN || z <= g.mz - 1 || g.has_hi);
+		double2 lamc[VD], rtc[HAS_RT ? VD : 1];
+		if (PFC) {
+#pragma unroll
+			for (int e = 0; e < VD; ++e) {
+				lamc[e] = lamn[e];
+				if (HAS_RT) rtc[HAS_RT ? e : 0] = rtn[HAS_RT ? e : 0];
+			}
+			if (z + 1 < z1) issue_coef(z + 1);
+		}
 #pragma unroll
 		for (int e = 0; e < VD; ++e) {
 			const long p = pb + off[e];
 			const int li = lidx[e];
 			Sten s0, s1;
-			const double2 lam = ld2s(a.lam + p);
+			const double2 lam = PFC ? lamc[e] : ld2s(a.lam + p);
 			const double xl = buf[li - 1], xr = buf[li + 2];
 			const double2 ym = ld2(buf + li - LW), yp = ld2(buf + li + LW);
 			s0.pc = pc[e].x; s1.pc = pc[e].y;
@@ -834,7 +867,7 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 				s += c1 ? vy : 0.;
 			};
 			if (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0) {
-				const double2 rt = ld2s(a.RT + p);
+				const double2 rt = PFC ? rtc[HAS_RT ? e : 0] : ld2s(a.RT + p);
 				add(acc[0], out.x * rt.x, out.y * rt.y);
 			} else if (KIND == KF_B0L) {
 				add(acc[0], pc[e].x * out.x, pc[e].y * out.y);

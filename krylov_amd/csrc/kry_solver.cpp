@@ -1400,10 +1400,14 @@ int run_iterations(kry_solver *h, int n_outer)
 	return h->status;
 }
 
-// Planes per chunk of the fused stencil kernels.  Long chunks re-read fewer halo planes, but
-// the grid should hold about a thousand blocks; and since all blocks take equally long, the
-// block count should fill the device's block slots a whole number of times, or leave a last
-// round that is at least mostly full.
+// Planes per chunk of the fused stencil kernels.  All blocks take equally long and a compute unit
+// that is left with one block draws only three quarters of its bandwidth share, so the block count
+// should fill the device's block slots a whole number of times.  Among the counts that do, the
+// smallest wins (the deepest chunks: fewer halo planes re-read, fewer block prologues, and the
+// blocks of a launch sweep the arrays in fewer fronts -- 512^3: 2 chunks of 256 planes run 2-8 %
+// faster than 8 of 64); a split whose exchange is to overlap with the interior chunks needs at
+// least 4.  Where no count fills the slots exactly (tile counts like 260 on general faces, small
+// grids) the older search applies: about a thousand blocks, and a last round that is mostly full.
 void choose_chunk_depth(kry_solver *h)
 {
 	if (h->zc_fixed) return;
@@ -1421,12 +1425,20 @@ void choose_chunk_depth(kry_solver *h)
 	const int per_cu = kry_fused_blocks_per_cu(h->ty, h->var, h->offd, h->op.exact_rcp != 0, h->gen);
 	if (per_cu > 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->slabs[0].device) == hipSuccess &&
 	    cus > 0) {
-		const double slots = (double)per_cu * cus;
-		for (int n = nch; (nz + n - 1) / n >= std::max(8, zc0 / 4); ++n) {
-			const double rounds = tiles * (double)n / slots;
-			const double last = rounds - std::floor(rounds);
-			if (rounds < 1.5) break;                     // the grid does not fill the device anyway
-			if (last == 0. || last >= 0.7 || rounds >= 12.) { nch = n; break; }
+		const long slots = (long)per_cu * cus;
+		const int n_min = (h->slabs.size() > 1 || h->np[2] > 1) ? 4 : 1;
+		int exact = 0;
+		for (int n = n_min; (n == n_min || (long)tiles * n <= 4 * slots) && (nz + n - 1) / n >= 8; ++n)
+			if (((long)tiles * n) % slots == 0) { exact = n; break; }
+		if (exact) {
+			nch = exact;
+		} else {
+			for (int n = nch; (nz + n - 1) / n >= std::max(8, zc0 / 4); ++n) {
+				const double rounds = tiles * (double)n / slots;
+				const double last = rounds - std::floor(rounds);
+				if (rounds < 1.5) break;                     // the grid does not fill the device anyway
+				if (last == 0. || last >= 0.7 || rounds >= 12.) { nch = n; break; }
+			}
 		}
 	}
 	h->zc = (nz + nch - 1) / nch;      // even chunks
