@@ -142,11 +142,11 @@ def slab_problem(n, nslabs, slab, workload, nz=None):
 
 # --------------------------------------------------------------------------- CPU leg
 
-def _cpu_run(n, L, workload, max_outer, eps, threads, split=None):
-    """One timed oracle solve in a child process (thread counts are fixed at start-up).
+def _cpu_start(n, L, workload, max_outer, eps, threads, split=None):
+    """Starts one timed oracle solve in a child process (thread counts are fixed at start-up).
     split: None = the serial restatement (or its OpenMP build when threads > 1);
     (px,py,pz) = the restatement of the reference's `-D parallel` path with one thread per
-    sub-domain of that Cartesian split."""
+    sub-domain of that Cartesian split.  The child times the solve itself (not its set-up)."""
     code = (
         "import sys, json, time, numpy as np\n"
         "sys.path.insert(0, %r)\n"
@@ -158,57 +158,86 @@ def _cpu_run(n, L, workload, max_outer, eps, threads, split=None):
         "var = %r in ('var', 'mixed')\n"
         "cfg = orc.make_cfg(f['mx'], f['delx'], f['bc'], L=%d, eps=%r, max_outer=%d, var_coef=var, "
         "use_offdiag=False, Dc=f['Dc'])\n"
-        "phi = f['phi'].copy()\n"
+        "phi = f['phi']\n"
         "z = np.zeros_like(phi) if var else None\n"
         "split = %r\n"
         "t0 = time.perf_counter()\n"
-        "if split: r = orc.solve_ranks(cfg, split, phi, f['rhs'].copy(), f['lam'].copy(), f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
-        "else: r = orc.solve(cfg, phi, f['rhs'].copy(), f['lam'].copy(), f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
+        "if split: r = orc.solve_ranks(cfg, split, phi, f['rhs'], f['lam'], f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
+        "else: r = orc.solve(cfg, phi, f['rhs'], f['lam'], f.get('Dxx'), f.get('Dyy'), f.get('Dzz'), z)\n"
         "print(json.dumps({'iters': r['iters'], 'seconds': time.perf_counter() - t0, 'status': r['status'],"
         " 'final': r['norm_final'] / r['norm_rhs']}))\n"
     ) % (ROOT, "orc.use_openmp_build()" if (threads > 1 and not split) else "", n, workload, workload, L, eps,
          max_outer, split)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    if out.returncode != 0:
-        raise RuntimeError(out.stderr.strip().splitlines()[-1] if out.stderr.strip() else "oracle run failed")
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])   # (the oracle prints the reference's NaN notes)
+    return subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _cpu_finish(proc, timeout=900):
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        raise RuntimeError("oracle run exceeded %d s" % timeout)
+    if proc.returncode != 0:
+        raise RuntimeError(err.strip().splitlines()[-1] if err.strip() else "oracle run failed")
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])   # (the oracle prints the reference's NaN notes)
     d["iters"] = max(d["iters"], 1)
     d["rate"] = d["iters"] / d["seconds"]
     return d
 
 
+def _cpu_run(n, L, workload, max_outer, eps, threads, split=None):
+    return _cpu_finish(_cpu_start(n, L, workload, max_outer, eps, threads, split))
+
+
 def cpu_baseline(L, workload, n_full, n_sample, iters, cores_wanted):
     """The CPU oracle next to the GPU line (kind "port": oracle/krylov_oracle.c restates the
     reference's serial path with its un-fused pass structure, oracle/krylov_oracle_ranks.c its
-    `-D parallel` path with the driver's Cartesian split, one thread per MPI rank):
-      * `value`: the headline workload at n_sample^3 for `iters` passes on P = 8 ranks
-        (2 x 2 x 2, BICGStab3D/main.C:146-150), scaled by grid points to n_full^3;
-      * `single_core`: the serial restatement, same sample, fewer passes;
+    `-D parallel` path with the driver's Cartesian split, one thread per MPI rank), timed on the
+    headline workload at its full size n_full^3:
+      * `value`: `iters` passes on P = 8 ranks (2 x 2 x 2, BICGStab3D/main.C:146-150);
+      * `single_core`: 3 passes of the serial restatement on one core;
+        (the two legs run side by side on 9 of the host's cores, after all GPU work)
+      * `sample_small`: the 8-rank leg once more at n_sample^3 (what earlier lines extrapolated from);
       * `c1`: the 64^3 plumbing case solved to 1e-6 in full on one core: the reference driver's
         test 1 (constant coefficients, l = 2) and the pure Poisson problem with l = 1 (its
         right-hand side is an eigenvector of the operator: one pass; with l = 2 the reference
         breaks down on it with "alpha is nan")."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    scale = ((n_sample + 1) ** 3) / float((n_full + 1) ** 3)
     desc = "%s-coefficient l=%d" % ("variable" if workload != "const" else "constant", L)
     out = {"unit": "iter/s", "kind": "port"}
-    one = _cpu_run(n_sample, L, workload, max(3, iters // 3), 0.0, 1)
-    out["single_core"] = {"value": one["rate"] * scale, "cores": 1, "measured_at_sample": one["rate"],
-                          "sample": "%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3, serial "
-                                    "restatement on 1 core; scaled by grid points to %d^3"
-                                    % (one["iters"], desc, n_sample, n_full)}
-    out.update(value=out["single_core"]["value"], cores=1, sample=out["single_core"]["sample"])
-    if avail >= 8 and cores_wanted >= 8:
+    many_ok = avail >= 8 and cores_wanted >= 8
+    side_by_side = many_ok and avail >= 9
+    p_many = _cpu_start(n_full, L, workload, iters, 0.0, 8, split=(2, 2, 2)) if many_ok else None
+    p_one = _cpu_start(n_full, L, workload, 3, 0.0, 1) if (side_by_side or not many_ok) else None
+    many = None
+    if p_many is not None:
         try:
-            many = _cpu_run(n_sample, L, workload, iters, 0.0, 8, split=(2, 2, 2))
-            out.update(value=many["rate"] * scale, cores=8, measured_at_sample=many["rate"],
-                       sample="%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3 on 8 host cores: "
-                              "restatement of the reference's MPI path, 2x2x2 sub-domains, one thread per rank, "
-                              "%.3f iter/s measured; scaled by grid points to %d^3"
-                              % (many["iters"], desc, n_sample, many["rate"], n_full))
+            many = _cpu_finish(p_many, 600)
         except Exception as e:
-            out["sample"] += " (8-rank run failed: %s)" % e
+            out["many_core_error"] = str(e)
+    if p_one is None:
+        p_one = _cpu_start(n_full, L, workload, 3, 0.0, 1)
+    one = _cpu_finish(p_one, 600)
+    out["single_core"] = {"value": one["rate"], "cores": 1,
+                          "sample": "%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3, serial "
+                                    "restatement on 1 core, %.1f s" % (one["iters"], desc, n_full, one["seconds"])}
+    out.update(value=one["rate"], cores=1, sample=out["single_core"]["sample"])
+    if many is not None:
+        out.update(value=many["rate"], cores=8,
+                   sample="%d passes (plus prologue/epilogue residuals) of the %s solve at %d^3 on 8 host cores: "
+                          "restatement of the reference's MPI path, 2x2x2 sub-domains, one thread per rank, %.1f s%s"
+                          % (many["iters"], desc, n_full, many["seconds"],
+                             "; the single-core leg ran beside it on a ninth core" if side_by_side else ""))
+        if n_sample and n_sample != n_full:
+            try:
+                small = _cpu_run(n_sample, L, workload, iters, 0.0, 8, split=(2, 2, 2))
+                out["sample_small"] = {"grid": n_sample, "value": small["rate"], "cores": 8, "passes": small["iters"],
+                                       "scaled_by_points_to_full_size": small["rate"] * ((n_sample + 1) ** 3)
+                                       / float((n_full + 1) ** 3)}
+            except Exception as e:
+                out["sample_small"] = {"grid": n_sample, "error": str(e)}
     out["c1"] = []
     for wl, cl, name in (("const", 2, "reference driver test 1 (D = 1,1,10; lambda = 0.2 x y^2 z)"),
                          ("poisson", 1, "Poisson (D = 1,1,1; lambda = 0)")):
@@ -277,6 +306,24 @@ def claim_stdout():
 
 
 # ---------------------------------------------------------------------- measurement
+
+def choose_headline(runs, transport, rccl_error, chosen_by_trial, trial_note):
+    """Which of the fully timed routes the line's `value` reports, and why.
+    runs: {route: {"valid": bool, "ms_per_step": float}} with "transport" always present.
+    The RCCL run whenever RCCL carried the transport and its run is valid; otherwise (RCCL could not
+    start, so the transport is the host-staged stand-in, or its run failed) the fastest valid run;
+    with no valid run at all the transport's (the caller reports the failure)."""
+    valid = {k: r for k, r in runs.items() if r.get("valid")}
+    if transport == "rccl" and "transport" in valid:
+        note = ("the trial's fastest route (%s) was timed in full as well, see `routes`" % chosen_by_trial
+                if chosen_by_trial != "transport" else "no faster valid route was found (%s)" % trial_note)
+        return "transport", "RCCL send/receive and all-reduce, the route the solver is specified on; " + note
+    if valid:
+        name = min(valid, key=lambda k: valid[k]["ms_per_step"])
+        return name, ("RCCL could not be used (%s): the transport here is the host-staged stand-in; headline = fastest "
+                      "valid full run of the routes timed (`routes`)" % (rccl_error or "its timed run failed"))
+    return "transport", "no route produced a valid run"
+
 
 def kernel_table(s0, s1, L, var, npts_local):
     """Per-kernel average launch time and algorithmic rate between two kry_stats snapshots."""
@@ -352,7 +399,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the ranks rendezvous, and rank 0 prints who took part (launcher check)")
-    ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=256)
+    ap.add_argument("--cpu-grid", dest="cpu_n", type=int, default=256,
+                    help="grid of the extra, small CPU sample (the CPU legs proper run at the GPU line's own size)")
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
 
@@ -455,9 +503,11 @@ def main():
     # all-reduced by the reduction kernels themselves through device mailboxes ("mailbox"), or
     # with the ghost planes travelling through mapped device memory as well ("mapped memory").
     # All are tried on a few passes of this very problem; the fastest one that reproduces the
-    # transport's residuals is used for the measurement.  KRY_BENCH_REDUCE=transport skips the
-    # trial, =mailbox / ="mapped memory" prefers that route when it is valid.
+    # transport's residuals is timed in full next to the transport (see run_route below).
+    # KRY_BENCH_REDUCE=transport skips the trial, =mailbox / ="mapped memory" prefers that route
+    # when it is valid.
     exchange, trial, why = "none", None, "one GPU: nothing to exchange"
+    mail_connected = False
     if world > 1:
         exchange, why = "transport", "KRY_BENCH_REDUCE=transport"
         want = os.environ.get("KRY_BENCH_REDUCE", "auto")
@@ -487,6 +537,7 @@ def main():
                 dist.all_gather_object(cerrs, cerr)
                 why = "the ranks' GPUs cannot map each other's memory (%s)" % next((e for e in cerrs if e), "?")
             else:
+                mail_connected = True
                 trial, hists = {}, {}
                 modes = {"mailbox": capi.KRY_MAIL_SUMS, "mapped memory": capi.KRY_MAIL_SUMS | capi.KRY_MAIL_PLANES,
                          "transport": 0}
@@ -518,7 +569,7 @@ def main():
                         best = name
                 solver.mail_enable(modes[best])
                 exchange = best
-                why = ("fastest of the routes tried on 6 passes of this problem that reproduces the transport's residuals"
+                why = ("the trial (6 passes of this problem per route) found none faster that reproduces the transport's residuals"
                        if want == "auto" else "KRY_BENCH_REDUCE=%s" % want)
                 trial = {k: (round(v, 4) if np.isfinite(v) else None) for k, v in trial.items()}
         barrier()
@@ -577,51 +628,98 @@ def main():
         dist.all_gather_object(got, mine)
         return all(g is not None and g[0] == 0 and g[1] == got[0][1] for g in got)
 
-    m = measure()
-    agree = None
-    if world > 1:
-        agree = ranks_agree(m)
-        if not agree and exchange != "transport":
-            # the mapped-memory route misbehaved on this machine: measure through the transport instead
-            why = "%s was chosen by the trial but the ranks' histories disagreed in the timed run; transport used" % exchange
-            exchange = "transport"
-            solver.mail_enable(0)
+    def probe_passes():
+        """Several GPUs: the timed region runs without per-kernel events (rank 0 would lag behind the
+        others by their cost); the kernel table, the roofline and the transport's share of a pass
+        come from a few extra passes with the events on.  Collective: every rank runs them or none."""
+        try:
+            solver.set_profile(True)
+            pa = solver.stats()
             barrier()
-            m = measure()
-            agree = ranks_agree(m)
-    if m is None or agree is False:
-        # (a collective decision: `agree` is the same on every rank)
+            tp = time.perf_counter()
+            solver.iterate(6)
+            ms = (time.perf_counter() - tp) / 6 * 1e3
+            pb = solver.stats()
+            solver.set_profile(False)
+            return 6, ms, pa, pb
+        except Exception as e:
+            sys.stderr.write("rank %d: no per-kernel times (%s)\n" % (rank, e))
+            return 0, None, None, None
+
+    def wait_shares(route, s0, s1, elapsed, probe):
+        """Share of a pass spent exchanging (rank 0): mapped-memory routes over the timed region
+        (the kernels count their own waiting), the transport over the probe passes (HIP events)."""
+        n_probe, probe_ms, pa, pb = probe
+        if n_probe and (pb.comm_wait_calls[0] or pb.comm_wait_calls[1]) and route != "mapped memory":
+            per = n_probe * probe_ms
+            ar = (pb.comm_wait_ms[0] - pa.comm_wait_ms[0]) / per
+            hl = (pb.comm_wait_ms[1] - pa.comm_wait_ms[1]) / per
+            basis = "HIP events around the transport's calls and the main stream's waits, %d probe passes" % n_probe
+            if route == "mailbox":
+                basis = "all-reduce: time counted by the reducing kernels; ghost planes: " + basis
+        else:
+            per = elapsed * 1e3
+            ar = (s1.comm_wait_ms[0] - s0.comm_wait_ms[0]) / per
+            hl = (s1.comm_wait_ms[1] - s0.comm_wait_ms[1]) / per
+            basis = "time counted by the waiting kernels themselves over the timed region"
+        return {"allreduce": round(ar, 4), "halo": round(hl, 4), "basis": basis}
+
+    def run_route(route):
+        """The whole timed run (stage, warm up, K passes between barriers, max over ranks) on one
+        exchange route, then the probe passes.  Returns what the line reports about it."""
+        if world > 1:
+            if mail_connected:
+                solver.mail_enable(modes[route])
+            barrier()
+        m = measure()
+        agree = ranks_agree(m) if world > 1 else None
+        if m is None or agree is False:
+            return {"route": route, "valid": False, "ranks_hold_identical_history": agree, "m": None}
+        t_stage, s0, s1, st, elapsed, hist = m
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt[0])
+        ok = (st == 0 and (restarts[0] > 0 or s1.iterations == args.warmup + args.steps) and np.all(np.isfinite(hist))
+              and agree is not False)
+        r = {"route": route, "valid": bool(ok), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+             "value": round(args.steps / elapsed, 3), "restarts": restarts[0], "ranks_hold_identical_history": agree,
+             "m": (t_stage, s0, s1, st, elapsed, hist), "probe": (0, None, None, None)}
+        if world > 1 and all_ok(ok):
+            r["probe"] = probe_passes()
+            r["wait_share_of_pass"] = wait_shares(route, s0, s1, elapsed, r["probe"])
+        return r
+
+    # One GPU: one run.  Several: the transport (RCCL send/receive and all-reduce -- the route the
+    # solver is specified on) is always timed for the full K passes; when the trial found a valid
+    # faster route through mapped device memory, that one is timed for the full K passes as well.
+    # The headline is the RCCL run; when RCCL itself could not start (the transport is then the
+    # host-staged stand-in, e.g. several ranks rehearsing on one GPU) it is the fastest valid run.
+    modes = {"mailbox": capi.KRY_MAIL_SUMS, "mapped memory": capi.KRY_MAIL_SUMS | capi.KRY_MAIL_PLANES, "transport": 0}
+    runs = {}
+    if world == 1:
+        head = run_route("none")
+    else:
+        chosen_by_trial = exchange
+        runs["transport"] = run_route("transport")
+        if chosen_by_trial != "transport":
+            runs[chosen_by_trial] = run_route(chosen_by_trial)
+        name, why = choose_headline(runs, transport, rccl["error"], chosen_by_trial, why)
+        head = runs[name]
+        exchange = head["route"]
+    if head.get("m") is None:
+        # (a collective decision: the flags are the same on every rank)
         if rank == 0:
             os.write(real_stdout, (json.dumps({"metric": METRIC, "value": None, "unit": "iter/s", "n_gpus": world,
                                                "valid": False, "error": "the timed run failed on a rank, or the ranks' residual histories differ",
                                                "config": {"transport": transport, "exchange": exchange}}) + "\n").encode())
         return 1
-    t_stage, s0, s1, st, elapsed, hist = m
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-    ok = (st == 0 and (restarts[0] > 0 or s1.iterations == args.warmup + args.steps) and np.all(np.isfinite(hist))
-          and agree is not False)
-
-    # Several GPUs: the timed region runs without per-kernel events (rank 0 would lag behind the
-    # others by their cost); the kernel table, the roofline and the transport's share of a pass
-    # come from a few extra passes with the events on.
-    probe, probe_ms = 0, None
-    sa, sb = s0, s1
-    if world > 1 and all_ok(ok):          # (a collective decision: every rank runs the extra passes or none)
-        try:
-            solver.set_profile(True)
-            sa = solver.stats()
-            probe = 6
-            barrier()
-            tp = time.perf_counter()
-            solver.iterate(probe)
-            probe_ms = (time.perf_counter() - tp) / probe * 1e3
-            sb = solver.stats()
-        except Exception as e:
-            sys.stderr.write("rank %d: no per-kernel times (%s)\n" % (rank, e))
-            probe = 0
+    t_stage, s0, s1, st, elapsed, hist = head["m"]
+    ok = head["valid"]
+    agree = head["ranks_hold_identical_history"]
+    restarts[0] = head["restarts"]
+    probe, probe_ms, pa_, pb_ = head["probe"]
+    sa, sb = (pa_, pb_) if probe else (s0, s1)
 
     if rank == 0:
         npts = float(n + 1) ** 2 * (nz + 1)
@@ -644,23 +742,12 @@ def main():
         moved = moved_words(L, var)
         whole = 8.0 * W * npts / (ms_step * 1e-3) / 1e9
         whole_moved = 8.0 * moved * npts / (ms_step * 1e-3) / 1e9
-        # share of a pass spent exchanging (rank 0): mapped-memory routes over the timed region
-        # (the kernels count their own waiting), the transport over the probe passes (HIP events)
-        wait = None
+        wait = head.get("wait_share_of_pass")
+        routes = None
         if world > 1:
-            if probe and (sb.comm_wait_calls[0] or sb.comm_wait_calls[1]) and exchange != "mapped memory":
-                base, per = sa, probe * probe_ms
-                ar = (sb.comm_wait_ms[0] - base.comm_wait_ms[0]) / per
-                hl = (sb.comm_wait_ms[1] - base.comm_wait_ms[1]) / per
-                basis = "HIP events around the transport's calls and the main stream's waits, %d probe passes" % probe
-                if exchange == "mailbox":
-                    basis = "all-reduce: time counted by the reducing kernels; ghost planes: " + basis
-            else:
-                per = args.steps * ms_step
-                ar = (s1.comm_wait_ms[0] - s0.comm_wait_ms[0]) / per
-                hl = (s1.comm_wait_ms[1] - s0.comm_wait_ms[1]) / per
-                basis = "time counted by the waiting kernels themselves over the timed region"
-            wait = {"allreduce": round(ar, 4), "halo": round(hl, 4), "basis": basis}
+            routes = {name: {k: r.get(k) for k in ("valid", "ms_per_step", "value", "restarts", "wait_share_of_pass",
+                                                   "ranks_hold_identical_history")} for name, r in runs.items()}
+            routes["transport"]["kind"] = transport
         out = {
             "metric": METRIC,
             "value": round(args.steps / elapsed, 3), "unit": "iter/s", "n_gpus": world,
@@ -679,7 +766,10 @@ def main():
                        "transport": transport, "rccl_ranks": rccl["ranks"], "rccl_error": rccl["error"],
                        "exchange": exchange, "exchange_reason": why,
                        "exchange_trial_ms_per_pass": trial, "wait_share_of_pass": wait,
-                       "ranks_hold_identical_history": agree},
+                       "ranks_hold_identical_history": agree,
+                       # every route's full timed run (K passes each); "rccl" repeats the transport's entry when
+                       # the transport is RCCL
+                       "routes": routes, "rccl": (routes["transport"] if routes and transport == "rccl" else None)},
             "valid": bool(ok), "solver_path": s1.fused, "restarts": restarts[0],
             "iteration_GBps": round(whole, 1),
             "iteration_frac_of_hbm_peak": round(whole / HBM_PEAK_GBS / world, 4),

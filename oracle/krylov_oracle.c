@@ -35,6 +35,37 @@
 static orc_reduce_hook g_hook = NULL;
 static void *g_hook_ctx = NULL;
 
+/* The reference's own cross-check handle: XOR of the raw bit patterns of every stored cell
+ * (ghost cells included), started from a fixed prime (solveLin_BICGStab.C:13-47).  The order
+ * in which the cells are visited does not matter. */
+unsigned long long orc_hash(const orc_cfg *c, const double *a)
+{
+	const long n = orc_store_size(c);
+	unsigned long long h = 797003437ULL;
+	for (long q = 0; q < n; ++q) {
+		unsigned long long bits;
+		memcpy(&bits, a + q, sizeof bits);
+		h ^= bits;
+	}
+	return h;
+}
+
+static unsigned long long *g_trace = NULL;
+static int g_trace_cap = 0, g_trace_n = 0;
+void orc_set_hash_trace(unsigned long long *buf, int cap)
+{
+	g_trace = buf;
+	g_trace_cap = buf ? cap : 0;
+	g_trace_n = 0;
+}
+int orc_hash_trace_count(void) { return g_trace_n; }
+static void trace(const orc_cfg *c, const double *a)
+{
+	if (!g_trace) return;
+	if (g_trace_n < g_trace_cap) g_trace[g_trace_n] = orc_hash(c, a);
+	g_trace_n++;
+}
+
 void orc_set_reduce_hook(orc_reduce_hook hook, void *ctx)
 {
 	g_hook = hook;
@@ -485,6 +516,10 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 		Dxx = Dyy = Dzz = Dxy = rhs;
 	}
 
+	trace(c, phi);                                           /* the print sites of :284-287 */
+	trace(c, rhs);
+	trace(c, lambda);
+
 	double normRHS = site_norm(ORC_SITE_NORM_RHS, 0, c, rhs);   /* :268 */
 	if (normRHS == 0.) normRHS = 1.;                         /* :269 */
 	o.norm_rhs = normRHS;
@@ -601,6 +636,8 @@ int orc_solve(const orc_cfg *c, double *phi, double *rhs, double *lambda,
 
 			norm = site_norm(ORC_SITE_NORM, iter_steps, c, r[0]);   /* :464 */
 			if (hist && iter_steps <= hist_cap) hist[iter_steps - 1] = norm;
+			trace(c, phi);                                   /* the print sites of :473-477 */
+			trace(c, r[0]);
 			if (c->debug > 2)                                /* :465-469 */
 				printf(" My error norm: %g %g %g %g %g \n", norm, sqrt(norm), eps * normRHS, eps,
 				       normRHS);

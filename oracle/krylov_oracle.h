@@ -88,6 +88,15 @@ typedef double (*orc_reduce_hook)(void *ctx, int site, int iter, int jj, const o
                                   const double *a, const double *b);
 void orc_set_reduce_hook(orc_reduce_hook hook, void *ctx);
 
+/* The reference's cross-check handle (solveLin_BICGStab.C:13-47): XOR of the raw bits of every
+ * stored cell of a field, started from 797003437.  With a trace buffer set, orc_solve records
+ * hash(phi), hash(rhs), hash(lambda) on entry (the reference's disabled prints at :284-287) and
+ * hash(phi), hash(residuals[0]) at the end of every pass (:473-477): what a build of the reference
+ * with those prints enabled must show.  orc_hash_trace_count: values recorded so far (may exceed cap). */
+unsigned long long orc_hash(const orc_cfg *cfg, const double *a);
+void orc_set_hash_trace(unsigned long long *buf, int cap);
+int  orc_hash_trace_count(void);
+
 /* gpu_order.c: repeat the sums in the order of the HIP kernels (fused tile rows
  * `ty`, planes per chunk `zc`, streaming-kernel grid target `stream_blocks`);
  * enable = 0 switches back to the reference order. */

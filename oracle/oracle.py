@@ -96,6 +96,12 @@ def lib():
         L.orc_gpu_order_slabs.argtypes = [C.c_int, C.c_int]
         L.orc_store_size.restype = C.c_long
         L.orc_store_size.argtypes = [P(OrcCfg)]
+        L.orc_hash.restype = C.c_ulonglong
+        L.orc_hash.argtypes = [P(OrcCfg), _dp]
+        L.orc_set_hash_trace.restype = None
+        L.orc_set_hash_trace.argtypes = [C.c_void_p, C.c_int]
+        L.orc_hash_trace_count.restype = C.c_int
+        L.orc_hash_trace_count.argtypes = []
         _lib = L
     return _lib
 
@@ -122,16 +128,38 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def solve(cfg, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4096):
+def hash_field(cfg, a):
+    """The reference's hash() of a field (BICGStab3D/solveLin_BICGStab.C:25-47): XOR of the raw bits of
+    every stored cell, started from 797003437."""
+    return int(lib().orc_hash(C.byref(cfg), a))
+
+
+def solve(cfg, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4096, hashes=False):
     """Run the oracle solve.  phi is updated in place.  Arrays are the
-    ghost-inclusive boxes, shape (mz+3, my+3, mx+3), C order (x fastest)."""
+    ghost-inclusive boxes, shape (mz+3, my+3, mx+3), C order (x fastest).
+    hashes: also record the reference's hash() at its own (disabled) print sites:
+    result["input_hashes"] = (phi, rhs, lambda) on entry (:284-287), result["pass_hashes"] =
+    [(phi, residuals[0]), ...] at the end of every pass (:473-477)."""
     hist = np.zeros(max(hist_cap, 1), dtype=np.float64)
     out = OrcOut()
-    st = lib().orc_solve(C.byref(cfg), phi, rhs, lam, _ptr(Dxx), _ptr(Dyy), _ptr(Dzz),
-                         _ptr(Dxy), hist, hist_cap, C.byref(out))
+    tr = np.zeros(3 + 2 * max(hist_cap, 1), dtype=np.uint64) if hashes else None
+    if hashes:
+        lib().orc_set_hash_trace(tr.ctypes.data_as(C.c_void_p), len(tr))
+    try:
+        st = lib().orc_solve(C.byref(cfg), phi, rhs, lam, _ptr(Dxx), _ptr(Dyy), _ptr(Dzz),
+                             _ptr(Dxy), hist, hist_cap, C.byref(out))
+        ntr = lib().orc_hash_trace_count() if hashes else 0
+    finally:
+        if hashes:
+            lib().orc_set_hash_trace(None, 0)
     n = min(out.iters, hist_cap)
-    return dict(status=st, iters=out.iters, norm_rhs=out.norm_rhs, norm_init=out.norm_init,
-                norm_final=out.norm_final, norm_true=out.norm_true, history=hist[:n].copy())
+    res = dict(status=st, iters=out.iters, norm_rhs=out.norm_rhs, norm_init=out.norm_init,
+               norm_final=out.norm_final, norm_true=out.norm_true, history=hist[:n].copy())
+    if hashes:
+        v = [int(x) for x in tr[:min(ntr, len(tr))]]
+        res["input_hashes"] = tuple(v[:3])
+        res["pass_hashes"] = [(v[i], v[i + 1]) for i in range(3, len(v) - 1, 2)]
+    return res
 
 
 def solve_ranks(cfg, nproc, phi, rhs, lam, Dxx=None, Dyy=None, Dzz=None, Dxy=None, hist_cap=4096):

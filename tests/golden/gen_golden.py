@@ -69,7 +69,7 @@ def run_case(name, mx, bc, var, offd, L, max_outer):
                        use_offdiag=offd, Dc=p.Dc)
     phi = p.phi.copy()
     cp = lambda a: None if a is None else a.copy()
-    r = orc.solve(cfg, phi, p.rhs.copy(), p.lam.copy(), cp(p.Dxx), cp(p.Dyy), cp(p.Dzz), cp(p.Dxy))
+    r = orc.solve(cfg, phi, p.rhs.copy(), p.lam.copy(), cp(p.Dxx), cp(p.Dyy), cp(p.Dzz), cp(p.Dxy), hashes=True)
     mid = (p.mx[2] // 2 + 1, p.mx[1] // 2 + 1)
     return {
         "name": name, "mx": list(p.mx), "bc": list(bc), "var": var, "offd": offd, "L": L,
@@ -79,6 +79,11 @@ def run_case(name, mx, bc, var, offd, L, max_outer):
         "history": [float(v).hex() for v in r["history"][:50]],
         "phi_sum": float(phi.sum()).hex(), "phi_abs_sum": float(np.abs(phi).sum()).hex(),
         "phi_centre_line": [float(v).hex() for v in phi[mid[0], mid[1], :]],
+        # the reference's own hash() (XOR of the raw bits of every stored cell, solveLin_BICGStab.C:25-47) at its
+        # disabled print sites: (phi, rhs, lambda) on entry (:284-287), (phi, residuals[0]) after every pass (:473-477)
+        "input_hashes": [str(v) for v in r["input_hashes"]],
+        "pass_hashes": [[str(a), str(b)] for a, b in r["pass_hashes"][:50]],
+        "phi_hash": str(orc.hash_field(cfg, phi)),
     }
 
 

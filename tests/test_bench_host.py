@@ -62,3 +62,22 @@ def test_kernel_byte_model_totals():
     assert sum(bench.kernel_words(1, True, False).values()) == 25       # contract: 26
     assert sum(bench.kernel_words(2, False, False).values()) <= 50
     assert sum(bench.kernel_words(2, True, False).values()) <= 62
+
+
+def test_headline_is_the_rccl_run_unless_rccl_is_out():
+    """Several GPUs: every route is timed in full; `value` reports the RCCL run whenever RCCL carried the
+    transport, also when a mapped-memory route was faster; without RCCL the fastest valid run."""
+    fast, slow = {"valid": True, "ms_per_step": 1.0}, {"valid": True, "ms_per_step": 2.0}
+    name, why = bench.choose_headline({"transport": slow, "mapped memory": fast}, "rccl", None, "mapped memory", "")
+    assert name == "transport" and "mapped memory" in why and "RCCL" in why
+    name, why = bench.choose_headline({"transport": slow}, "rccl", None, "transport", "cannot map")
+    assert name == "transport" and "cannot map" in why
+    # RCCL refused (ranks sharing a GPU): host-staged stand-in, the fastest valid run leads and the line says why
+    name, why = bench.choose_headline({"transport": slow, "mapped memory": fast}, "gloo-staged (RCCL refused)",
+                                      "2 ranks on one device", "mapped memory", "")
+    assert name == "mapped memory" and "2 ranks on one device" in why
+    # RCCL's own run failed: the other route, with the reason
+    name, why = bench.choose_headline({"transport": {"valid": False}, "mailbox": slow}, "rccl", None, "mailbox", "")
+    assert name == "mailbox" and "failed" in why
+    name, _ = bench.choose_headline({"transport": {"valid": False}}, "rccl", None, "transport", "")
+    assert name == "transport"

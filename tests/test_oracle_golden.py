@@ -30,9 +30,46 @@ def test_oracle_reproduces_fixture(orc, case):
         assert got[key] == want[key], key
     assert got["history"] == want["history"]
     assert got["phi_centre_line"] == want["phi_centre_line"]
+    # every stored cell of phi and of the residual, after every pass, bit for bit
+    assert got["input_hashes"] == want["input_hashes"]
+    assert got["pass_hashes"] == want["pass_hashes"]
+    assert got["phi_hash"] == want["phi_hash"]
 
 
 def test_hash_field_is_exact():
     a = gen_golden.hash_field((5, 4, 3), 7)
     assert a.min() >= -1.0 and a.max() < 1.0
     assert np.all(a * (1 << 20) == np.round(a * (1 << 20)))
+
+
+def test_reference_hash_is_an_xor_of_raw_bits(orc):
+    """BICGStab3D/solveLin_BICGStab.C:13-47: start 797003437, XOR with the bit pattern of every stored cell."""
+    cfg = orc.make_cfg((2, 3, 4), (0.5, 0.25, 0.125))
+    a = np.zeros((7, 6, 5))
+    assert orc.hash_field(cfg, a) == 797003437
+    a[3, 2, 1] = 1.0
+    a[0, 0, 0] = -0.0                      # a ghost corner counts, and so does the sign of a zero
+    want = 797003437 ^ 0x3FF0000000000000 ^ 0x8000000000000000
+    assert orc.hash_field(cfg, a) == want
+    assert orc.hash_field(cfg, a[::-1, ::-1, ::-1].copy()) == want      # the order of the cells does not matter
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(a.shape)
+    assert orc.hash_field(cfg, b) == 797003437 ^ int(np.bitwise_xor.reduce(b.view(np.uint64).ravel()))
+
+
+def test_c1_hash_sequences(orc):
+    """The 64^3 plumbing case of the reference driver (test 1, l = 2, eps 1e-6) in the reference's own
+    summation order: hash(phi), hash(residual) after every pass as committed in tests/golden/c1_hashes.json --
+    the sequence a build of the reference with its hash prints enabled can be diffed against
+    (oracle/print_hashes.py prints it in the reference's format).  The inputs contain sin(): where the host's
+    libm / numpy give other bits for them than on the machine that wrote the fixture, the sequences cannot
+    be compared and the test says so."""
+    import gen_c1_hashes
+    with open(os.path.join(HERE, "golden", "c1_hashes.json")) as f:
+        want = json.load(f)
+    got = gen_c1_hashes.run()
+    if got["input_hashes"] != want["input_hashes"]:
+        pytest.skip("this host's sin() gives other input bits than the fixture's host")
+    assert got["iters"] == want["iters"] and got["status"] == want["status"]
+    assert got["pass_hashes"] == want["pass_hashes"]
+    assert got["returned_phi_hash"] == want["returned_phi_hash"]
