@@ -212,6 +212,10 @@ int kry_load_var(kry_handle h, const double *phi, const double *rhs, const doubl
                  int use_offdiag);
 int kry_iterate(kry_handle h, int n_outer);
 int kry_fetch_phi(kry_handle h, double *phi);
+/* The current residuals[0] of the loop (solveLin_BICGStab.C:294-299 before the first pass, :451-462
+ * after a pass), in the host layout: what the reference's disabled per-pass print hashes next to phi
+ * (solveLin_BICGStab.C:472-477).  For stepping drivers and cross-checks; the solve does not need it. */
+int kry_fetch_residual(kry_handle h, double *r0);
 
 /* Repeated solves with the coefficients resident on the device: what a time-stepping caller of
  * Linsolver3D::solve does next (BICGStab3D/LinSolver3D.hpp:31-46 carries delt / evolve_time for

@@ -26,7 +26,7 @@ STATUS = {0: "ok", 1: "alpha is nan", 3: "norm is nan", 4: "iteration cap reache
 SYMBOLS = [
     "kry_create", "kry_destroy", "kry_comm_unique_id", "kry_comm_init", "kry_comm_init_callbacks", "kry_comm_init_host_callbacks", "kry_device_check",
     "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
-    "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi",
+    "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi", "kry_fetch_residual",
     "kry_update_rhs", "kry_update_phi", "kry_update_lambda", "kry_reset", "kry_resolve",
     "kry_set_profile", "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_op_dot_static", "kry_status_string", "kry_last_error",
@@ -143,6 +143,8 @@ def lib():
     L.kry_iterate.argtypes = [vp, ci]
     L.kry_fetch_phi.restype = ci
     L.kry_fetch_phi.argtypes = [vp, _dp]
+    L.kry_fetch_residual.restype = ci
+    L.kry_fetch_residual.argtypes = [vp, _dp]
     L.kry_set_profile.restype = ci
     L.kry_set_profile.argtypes = [vp, ci]
     L.kry_get_stats.restype = ci
@@ -335,6 +337,9 @@ class Solver:
 
     def fetch_phi(self, phi):
         return _check(lib().kry_fetch_phi(self._h, phi), "kry_fetch_phi")
+
+    def fetch_residual(self, r0):
+        return _check(lib().kry_fetch_residual(self._h, r0), "kry_fetch_residual")
 
     def stats(self):
         s = KryStats()

@@ -298,6 +298,19 @@ void BICGStab::solve(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMa
 	solve_int(bounds, phi, rhs, lambda, Dxx, Dyy, Dzz, none, debug_);
 }
 
+unsigned long long BICGStab::hash(const NumMatrix<double, 3> &m)
+{
+	// BICGStab3D/solveLin_BICGStab.C:13-47
+	unsigned long long h = 797003437ULL;
+	const double *p = m.data();
+	for (size_t q = 0; q < m.size(); ++q) {
+		unsigned long long bits;
+		memcpy(&bits, p + q, sizeof bits);
+		h ^= bits;
+	}
+	return h;
+}
+
 void BICGStab::solve_int(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, NumMatrix<double, 3> &rhs,
                          NumMatrix<double, 3> &lambda, NumMatrix<double, 3> &Dxx, NumMatrix<double, 3> &Dyy,
                          NumMatrix<double, 3> &Dzz, NumMatrix<double, 3> &Dxy, int debug_)
@@ -315,7 +328,40 @@ void BICGStab::solve_int(BoundaryHandler3D &bounds, NumMatrix<double, 3> &phi, N
 	for (int k = 0; k < 5; ++k) last_coef[k] = coef[k];
 	for (int k = 0; k < 3; ++k) last_diag[k] = DiffDiag[k];
 	last_mode = keep_coefficients ? mode : -1;   // arrays may change freely while the switch is off
-	if (same) {
+	if (hash_trace) {
+		// the inputs as the reference would print them (:284-287), then pass by pass (:472-477: its line converts
+		// the 64-bit value to double and prints 6 digits; the exact integers follow on a line of their own)
+		if (rank == 0) {
+			cout << "Input variables:" << endl;
+			cout << "\thash(phi)     = " << hash(phi) << endl;
+			cout << "\thash(rhs)     = " << hash(rhs) << endl;
+			cout << "\thash(lambda)  = " << hash(lambda) << endl;
+		}
+		st = use_spatialDiffusion
+		         ? kry_load_var(handle, phi.data(), rhs.data(), lambda.data(), Dxx.data(), Dyy.data(), Dzz.data(), dxy, dxy != NULL)
+		         : kry_load_const(handle, phi.data(), rhs.data(), lambda.data(), DiffDiag[0], DiffDiag[1], DiffDiag[2]);
+		NumMatrix<double, 3> res = phi;
+		kry_stats ks;
+		int before = -1;
+		while (st == KRY_OK) {
+			st = kry_iterate(handle, 1);
+			kry_get_stats(handle, &ks);
+			if (st < 0 || ks.iterations == before) break;      // converged (or stopped) before this call: no pass ran
+			before = ks.iterations;
+			if (kry_fetch_phi(handle, phi.data()) < 0 || kry_fetch_residual(handle, res.data()) < 0) { st = KRY_ERR_HIP; break; }
+			if (rank == 0) {
+				const unsigned long long hp = hash(phi), hr = hash(res);
+				cout << " hash(phi) = " << (double)hp << ", hash(residual) " << (double)hr << endl;
+				cout << " [exact, pass " << ks.iterations << "] hash(phi) = " << hp << ", hash(residual) = " << hr << endl;
+			}
+			if (ks.norm_final <= eps * ks.norm_rhs) break;     // :496
+		}
+		if (st >= 0) {
+			int st2 = kry_fetch_phi(handle, phi.data());
+			if (st2 < 0) st = st2;
+		}
+		last_mode = -1;
+	} else if (same) {
 		// the operator is on the device already: stage phi and rhs, re-run the prologue, solve
 		st = kry_update_phi(handle, phi.data());
 		if (st >= 0) st = kry_update_rhs(handle, rhs.data());

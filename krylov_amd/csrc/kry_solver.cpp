@@ -2009,6 +2009,20 @@ int kry_fetch_phi(kry_handle h, double *phi)
 	return finish_solve(h, phi);
 }
 
+int kry_fetch_residual(kry_handle h, double *r0)
+{
+	if (!h || !r0) return KRY_ERR_ARG;
+	if (!h->loaded) { set_err("no problem loaded"); return KRY_ERR_STATE; }
+	// residuals[0] alternates between its two copies with the pass on the fused path
+	const int copy = h->fused ? (h->it_base & 1) : 0;
+	double t0 = now_ms();
+	for (size_t i = 0; i < h->slabs.size(); ++i) CHK(download(h, h->slabs[i], (int)i, h->slabs[i].rb[0][copy], r0));
+	CHK(sync_all(h));
+	for (Slab &s : h->slabs) drop_stage(s);
+	h->stage_ms += now_ms() - t0;
+	return KRY_OK;
+}
+
 static int solve_tail(kry_handle h, double *phi, int debug)
 {
 	h->debug = debug;

@@ -62,6 +62,7 @@ struct Options {
 	double tol = default_tolerance;
 	int max_iter = 0;
 	bool stats = false;
+	bool hashes = false;    // the reference's disabled hash prints (solveLin_BICGStab.C:284-287, 472-477)
 	bool quiet = false;
 	unsigned seed = 12345;
 	int nproc[3] = {0, 0, 0};   // -D parallel: process grid (0 = choose from the process count)
@@ -84,6 +85,8 @@ void usage(const char *argv0)
 	cout << "    -s   --seed SEED              Seed for --randomize" << endl;
 	cout << "         --stats                  Print one tab-separated row instead of the report" << endl;
 	cout << "    -q   --quiet                  No per-iteration output" << endl;
+	cout << "         --hashes                 Print the reference's hash() of the inputs and, after every pass, of phi" << endl;
+	cout << "                                  and the residual (its disabled prints, solveLin_BICGStab.C:284-287, 472-477)" << endl;
 #ifdef WITH_HDF5
 	cout << "    -o   --output FILE            Write phi, phi_ana and rhs to an HDF5 field file" << endl;
 	cout << "         --restart FILE           Initial guess: phi of an HDF5 field file" << endl;
@@ -116,6 +119,7 @@ bool parse(int argc, char **argv, Options &o)
 		else if (a == "-s" || a == "--seed") o.seed = (unsigned)atol(need("Seed"));
 		else if (a == "--nproc") { for (int d = 0; d < 3; ++d) o.nproc[d] = atoi(need("Process grid")); }
 		else if (a == "--stats") o.stats = true;
+		else if (a == "--hashes") o.hashes = true;
 		else if (a == "-q" || a == "--quiet") o.quiet = true;
 #ifdef WITH_HDF5
 		else if (a == "-o" || a == "--output") o.output = need("Output file");
@@ -269,6 +273,7 @@ int main(int argc, char *argv[])
 	lin_solver->setup(grid_x, grid_y, grid_z, opt.tol, pars, false, false, opt.max_iter);
 #endif
 
+	if (opt.hashes) static_cast<BICGStab *>(lin_solver)->set_HashTrace(true);
 	if (talk) cout << " lösen " << endl;
 	const int dbg = (opt.quiet || opt.stats) ? 0 : 8;
 	const auto t0 = chrono::steady_clock::now();

@@ -2,12 +2,12 @@
 import numpy as np
 
 
-def oracle_solve(orc, p, L=2, eps=1e-6, max_outer=0):
+def oracle_solve(orc, p, L=2, eps=1e-6, max_outer=0, hashes=False):
     cfg = orc.make_cfg(p.mx, p.delx, p.bc, L=L, eps=eps, max_outer=max_outer, var_coef=p.var_coef,
                        use_offdiag=p.use_offdiag, Dc=p.Dc)
     phi = p.phi.copy()
     cp = lambda a: None if a is None else a.copy()
-    r = orc.solve(cfg, phi, p.rhs.copy(), p.lam.copy(), cp(p.Dxx), cp(p.Dyy), cp(p.Dzz), cp(p.Dxy))
+    r = orc.solve(cfg, phi, p.rhs.copy(), p.lam.copy(), cp(p.Dxx), cp(p.Dyy), cp(p.Dzz), cp(p.Dxy), hashes=hashes)
     r["phi"] = phi
     return r
 

@@ -242,3 +242,29 @@ def test_plain_c_caller_solves_the_reference_drivers_first_test():
         m = re.search(r"passes (\d+) .* l2 error (\S+)  kernels (\w+)", out.stdout)
         assert m and 3 < int(m.group(1)) < 300 and m.group(3) == "fused"
         assert 0.5e-4 < float(m.group(2)) < 3e-4          # (pi h)^2 / 12 * O(1) at h = 1/64
+
+
+@pytest.mark.parametrize("test,n", [(1, 64), (2, 24)])
+def test_driver_prints_the_reference_hashes(orc, test, n):
+    """`bicgstab --hashes`: the reference's hash() (XOR of the raw bits of every stored cell,
+    BICGStab3D/solveLin_BICGStab.C:25-47) of the inputs and, after every pass, of phi and residuals[0], at the
+    places of the reference's disabled prints (:284-287, 472-477).  Every stored cell of both fields -- ghost
+    cells and the signs of zeros included -- equals the oracle's in device order after every pass."""
+    out = subprocess.run([DRIVER, "-n", str(n), "-t", str(test), "-q", "--hashes"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    txt = out.stdout
+    ins = [int(v) for v in re.findall(r"\thash\((?:phi|rhs|lambda)\)\s+= (\d+)", txt)]
+    exact = [(int(a), int(b)) for a, b in re.findall(r"\[exact, pass \d+\] hash\(phi\) = (\d+), hash\(residual\) = (\d+)", txt)]
+    lines = re.findall(r"^ hash\(phi\) = (\S+), hash\(residual\) (\S+)$", txt, flags=re.M)
+    p = {1: P.reference_test1, 2: P.reference_test2}[test](n)
+    got = capi.solve_problem(p, L=2, eps=1e-6)
+    ty, zc, sb = got["order"]
+    orc.use_gpu_order(1, ty, zc, sb)
+    try:
+        want = oracle_solve(orc, p, L=2, eps=1e-6, hashes=True)
+    finally:
+        orc.use_gpu_order(0)
+    assert ins == list(want["input_hashes"])
+    assert len(exact) == want["iters"] == got["iters"] and len(lines) == len(exact)
+    assert exact == want["pass_hashes"]
+    assert [float(a) for a, _ in lines] == [float("%g" % float(a)) for a, _ in exact]     # the reference's own line format

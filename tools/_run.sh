@@ -1,4 +1,3 @@
 set -e
-timeout -k 10 500 python3 -u bench.py > gpurun_out/r3k_bench512.json 2> gpurun_out/r3k.err
-timeout -k 10 300 python3 -u bench.py --gpus 2 --no-cpu --steps 20 > gpurun_out/r3k_two_ranks.json 2>> gpurun_out/r3k.err
+timeout -k 10 500 python -u -m pytest tests/test_gpu_compat.py tests/test_gpu_resident.py -x -q --timeout 180 --timeout-method thread > gpurun_out/r3l_tests.log 2>&1
 echo ok
