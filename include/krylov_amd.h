@@ -281,6 +281,11 @@ int kry_op_l2norm(kry_handle h, const double *v, double *result);
  *     HIP device `device`; the call neither synchronises nor allocates: the kernel's
  *     partial sums and ticket live in a file-scope device array of about 33 KB that
  *     every GPU the library runs on holds until the process ends.
+ * The array's address on a GPU is asked from the runtime once per GPU, which may load the
+ * library's code there (and allocate): kry_device_check(device) and kry_create do that, so
+ * call one of them for the device -- or make one warm-up call of this function -- before
+ * the first call inside a stream capture; every later call only queues a 256-byte memset
+ * and one kernel, both of which a capture records.
  * Fields of more than KRY_STATIC_DOT_MAX_DOUBLES doubles (ghosts included) are refused
  * with KRY_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in
  * time on one GPU (different streams, or threads) race; calls ordered on one stream do not. */

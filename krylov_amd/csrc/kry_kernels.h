@@ -118,5 +118,6 @@ hipError_t kry_launch_wdot(const KryGeo &g, const double *x, const double *y, in
                            hipStream_t st);
 // The weighted dot with its partial sums and ticket in a file-scope device array instead of
 // allocated memory (see kry_op_dot_static in include/krylov_amd.h).
+hipError_t kry_static_scratch_ready(int device, double **out);
 hipError_t kry_launch_wdot_static(int device, const KryGeo &g, const double *x, const double *y, int norm_mode,
                                   double *result, hipStream_t st);

@@ -2027,18 +2027,32 @@ static __device__ __align__(256) double kry_static_scratch[KRY_STATIC_PARTIALS +
 #define KRY_STATIC_MAX_DEVICES 64
 static double *g_static_ptr[KRY_STATIC_MAX_DEVICES];   // address of the array on each device, 0 = not asked yet
 
-// Calls on one GPU share that GPU's array: two of them in flight at once race.
-hipError_t kry_launch_wdot_static(int device, const KryGeo &g, const double *x, const double *y, int norm_mode,
-                                  double *result, hipStream_t st)
+// The address of the array on `device` (which the caller has made current), asked from the runtime once
+// per device.  That first request may load the code object on the device -- it can allocate, and it is
+// not a call to make while a stream capture is open -- so the library makes it where it initialises a
+// device (kry_device_check, kry_create); the entry point itself only repeats it for a device neither has seen.
+hipError_t kry_static_scratch_ready(int device, double **out)
 {
 	if (device < 0 || device >= KRY_STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
 	double *scratch = __atomic_load_n(&g_static_ptr[device], __ATOMIC_ACQUIRE);
 	if (!scratch) {
-		// once per device, with that device current (the caller made it so)
 		hipError_t e = hipGetSymbolAddress((void **)&scratch, HIP_SYMBOL(kry_static_scratch));
 		if (e != hipSuccess) return e;
 		if (!scratch) return hipErrorInvalidSymbol;
 		__atomic_store_n(&g_static_ptr[device], scratch, __ATOMIC_RELEASE);
+	}
+	if (out) *out = scratch;
+	return hipSuccess;
+}
+
+// Calls on one GPU share that GPU's array: two of them in flight at once race.
+hipError_t kry_launch_wdot_static(int device, const KryGeo &g, const double *x, const double *y, int norm_mode,
+                                  double *result, hipStream_t st)
+{
+	double *scratch = nullptr;
+	{
+		hipError_t e = kry_static_scratch_ready(device, &scratch);
+		if (e != hipSuccess) return e;
 	}
 	const long rows = (long)(g.my + 1) * (g.mz + 1);
 	dim3 grid((unsigned)std::min<long>((rows + NW - 1) / NW, KRY_WDOT_BLOCKS)), block(NT);

@@ -1604,6 +1604,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 			s.index = h->d.slab_begin + i;
 			s.device = d->devices[i];
 			HIPCHK(hipSetDevice(s.device));
+			HIPCHK(kry_static_scratch_ready(s.device, nullptr));   // (see kry_device_check)
 			HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
 			HIPCHK(hipStreamCreateWithFlags(&s.st_comm, hipStreamNonBlocking));
 			HIPCHK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
@@ -1773,6 +1774,13 @@ int kry_device_check(int device)
 	          hipMemcpy(&w, d, sizeof w, hipMemcpyDeviceToHost) == hipSuccess && w == v;
 	if (d) hipFree(d);
 	if (!ok) { set_err("device %d does not accept work", device); return KRY_ERR_HIP; }
+	// the allocation-free entry point's scratch array: its address on this device, asked here once so
+	// that kry_op_dot_static itself never has to (that request may load code and allocate)
+	if (kry_static_scratch_ready(device, nullptr) != hipSuccess) {
+		(void)hipGetLastError();
+		set_err("device %d: the static scratch array has no address", device);
+		return KRY_ERR_HIP;
+	}
 	return KRY_OK;
 }
 

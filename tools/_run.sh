@@ -1,3 +1,3 @@
 set -e
-timeout -k 10 500 python -u -m pytest tests/test_gpu_compat.py tests/test_gpu_resident.py -x -q --timeout 180 --timeout-method thread > gpurun_out/r3l_tests.log 2>&1
+timeout -k 10 300 python -u -m pytest tests/test_zz_no_alloc.py -x -q --timeout 120 --timeout-method thread > gpurun_out/r3m_tests.log 2>&1
 echo ok
