@@ -1,3 +1,5 @@
 set -e
-timeout -k 10 300 python -u -m pytest tests/test_zz_no_alloc.py -x -q --timeout 120 --timeout-method thread > gpurun_out/r3m_tests.log 2>&1
+tools/r3_profile_const256.sh r3
+tools/collect_profiles.sh r3_var var
+tools/collect_profiles.sh r3_var_l1 var --ell 1
 echo ok
