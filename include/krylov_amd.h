@@ -104,6 +104,8 @@ typedef struct kry_stats {
 	int    rccl_ranks;       /* ranks of the RCCL communicator (ncclCommCount), 0: none in use */
 	int    staged_fields;    /* fields copied into the library for the last solve: 3 or 6-7 after a load /
 	                            full solve, only the replaced ones after kry_update_* + kry_resolve */
+	int    overlapped_exchanges; /* Cartesian split: stencil launches since the last load that ran their inner tiles
+	                            while the ghost cells of their input were still being exchanged */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;

@@ -72,6 +72,7 @@ class KryStats(C.Structure):
         ("comm_wait_calls", C.c_int * 2),
         ("rccl_ranks", C.c_int),
         ("staged_fields", C.c_int),
+        ("overlapped_exchanges", C.c_int),
     ]
 
 

@@ -48,6 +48,10 @@ public:
 	int set_link(int rank, char *self, const std::vector<char *> &peer, size_t cap, long long timeout, KryState *S);
 	void link_planes(bool on) { link_on_ = on && link_self_ != nullptr; }
 	bool link_planes() const { return link_on_; }
+	// how halo() moves the planes: through library calls that involve the communicator (RCCL), or
+	// through caller-supplied callbacks, which return only when the planes have arrived
+	bool halo_by_rccl() const { return !link_on_ && !cb_halo_ && comm_ != nullptr; }
+	bool halo_blocks_host() const { return !link_on_ && cb_halo_ != nullptr; }
 
 private:
 	void *comm_ = nullptr;

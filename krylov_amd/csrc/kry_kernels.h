@@ -51,7 +51,9 @@ struct KryFused {
 	int zc;                  // planes per chunk
 	int ntx, nty, nchunk;
 	int nblk;                // blocks of THIS launch
-	int ch_sel;              // 0: all chunks, 1: chunk 0 and the last n_edge-1 chunks, 2: the chunks in between
+	int ch_sel;              // 0: all chunks, 1: chunk 0 and the last n_edge-1 chunks, 2: the chunks in between,
+	                         // 3: the tiles inside the box ib (they read no cell an exchange fills), 4: all others
+	int ib[6];               // ch_sel 3, 4: tx0, tx1, ty0, ty1, ch0, ch1 (inclusive) of the inner tiles
 	int n_edge;              // 2 or 3
 	int blk_off;             // offset of this launch's blocks in the partial-sum array
 	int rev;                 // 1: the blocks take the tiles in reverse order (every kernel starts where the one

@@ -557,13 +557,52 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 		bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 		if (a.rev) bid = nb - 1 - bid;
 	}
-	const int tx = bid % a.ntx;
-	const int ty = (bid / a.ntx) % a.nty;
+	int tx = bid % a.ntx;
+	int ty = (bid / a.ntx) % a.nty;
 	int ch = bid / (a.ntx * a.nty);
 	// a launch covers all chunks, the outermost ones (chunk 0 and the last n_edge-1
 	// chunks: those holding the planes the neighbours need), or the ones in between
 	if (a.ch_sel == 1) ch = ch ? a.nchunk - a.n_edge + ch : 0;
 	else if (a.ch_sel == 2) ch += 1;
+	else if (a.ch_sel >= 3) {
+		// the tiles inside / outside a box of tile indices; either way a tile keeps the partial-sum
+		// slot it has in the undivided launch
+		const int nxi = a.ib[1] - a.ib[0] + 1, nyi = a.ib[3] - a.ib[2] + 1, nci = a.ib[5] - a.ib[4] + 1;
+		int r = bid;
+		if (a.ch_sel == 3) {
+			tx = a.ib[0] + r % nxi;
+			ty = a.ib[2] + (r / nxi) % nyi;
+			ch = a.ib[4] + r / (nxi * nyi);
+		} else {
+			const int plane_tiles = a.ntx * a.nty;
+			const int n1 = (a.nchunk - nci) * plane_tiles;             // whole chunks outside
+			const int row_tiles = (a.nty - nyi) * a.ntx;               // whole tile rows outside, per inner chunk
+			const int n2 = nci * row_tiles;
+			if (r < n1) {
+				const int c = r / plane_tiles;
+				ch = c < a.ib[4] ? c : c + nci;
+				r -= c * plane_tiles;
+				ty = r / a.ntx;
+				tx = r % a.ntx;
+			} else if (r < n1 + n2) {
+				r -= n1;
+				ch = a.ib[4] + r / row_tiles;
+				r %= row_tiles;
+				const int y = r / a.ntx;
+				ty = y < a.ib[2] ? y : y + nyi;
+				tx = r % a.ntx;
+			} else {
+				r -= n1 + n2;
+				const int col_tiles = a.ntx - nxi;                     // tiles outside per inner row
+				ch = a.ib[4] + r / (nyi * col_tiles);
+				r %= nyi * col_tiles;
+				ty = a.ib[2] + r / col_tiles;
+				const int x = r % col_tiles;
+				tx = x < a.ib[0] ? x : x + nxi;
+			}
+		}
+		bid = (ch * a.nty + ty) * a.ntx + tx;
+	}
 
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int z0 = a.zlo + ch * a.zc;

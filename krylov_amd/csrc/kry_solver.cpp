@@ -129,12 +129,14 @@ struct kry_solver {
 	int it_base = 0;           // outer iterations completed (mirrors S->iter)
 	int status = 0;
 	bool done = false;
+	bool halo_pending = false;  // an exchange of an operator output is running on the exchange stream (Cartesian split)
 	bool alt = true;            // every kernel of a pass takes its work in the opposite order of the one before it
 	bool tail_bc_done = false;  // the post-loop do_BCs(phi) of a constant-coefficient solve has been applied
 	double norm_rhs = 0, norm_init = 0, norm_final = 0;
 	double solve_ms = 0, stage_ms = 0;
 	double pending_stage_ms = 0;   // staging done by kry_update_* since the last solve
 	int staged_fields = 0;         // field copies into the library for the current / last solve
+	int overlapped_exchanges = 0;  // stencil launches split around a pending exchange since the last load
 	double enqueue_ms = 0;     // host time spent queueing the passes of the last run
 	std::vector<double> hist;  // generic path history (fused path keeps it on the device)
 	// two consecutive passes (even, odd: the ping-pong buffers swap roles) captured as a
@@ -291,6 +293,7 @@ void prof_collect(kry_solver *h)
 // Make the values of S->sums identical on every slab of every process: the sum
 // over all slabs, added in slab order.  No-op for a single slab (the kernel's
 // last block already advanced the recurrences).
+int halo_wait(kry_solver *h);
 int reduce_sums(kry_solver *h, int phase)
 {
 	const int ns = (int)h->slabs.size();
@@ -314,6 +317,9 @@ int reduce_sums(kry_solver *h, int phase)
 		HIPCHK(kry_launch_sum_slabs(s0.gather, ns, tot, s0.st));
 	}
 	if (remote) {
+		// (RCCL: the library's calls on one communicator stay in one order on one stream at a time -- a pending
+		// exchange on the exchange stream is let finish first)
+		if (h->comm.halo_by_rccl()) CHK(halo_wait(h));
 		prof_begin(h, s0, 8);
 		CHK(h->comm.allreduce_sum(tot, KRY_NSUMS, s0.st));
 		prof_end(h, s0);
@@ -345,7 +351,7 @@ int reduce_sums(kry_solver *h, int phase)
 // hops as in BoundaryHandler.C:579-1045.  In x the interface plane travels too (0 ->
 // the lower neighbour's mx): the fused kernels evaluate the operator on the upper
 // side of an x interface only.
-int exchange_xy(kry_solver *h, double *f)
+int exchange_xy(kry_solver *h, double *f, hipStream_t st)
 {
 	Slab &s = h->slabs[0];
 	const KryGeo &g = s.g;
@@ -365,19 +371,19 @@ int exchange_xy(kry_solver *h, double *f)
 		if (g.nb[2 * dir]) { cc[dir] -= 1; peer_lo = h->rank_of(cc[0], cc[1], cc[2]); cc[dir] += 1; }
 		if (g.nb[2 * dir + 1]) { cc[dir] += 1; peer_hi = h->rank_of(cc[0], cc[1], cc[2]); cc[dir] -= 1; }
 		if (peer_lo >= 0) {
-			HIPCHK(kry_launch_face(f, send_lo, g, dir, 1, true, s.st));
-			if (nl == 2) HIPCHK(kry_launch_face(f, send_lo + n, g, dir, 0, true, s.st));
+			HIPCHK(kry_launch_face(f, send_lo, g, dir, 1, true, st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, send_lo + n, g, dir, 0, true, st));
 		}
 		if (peer_hi >= 0) {
-			HIPCHK(kry_launch_face(f, send_hi, g, dir, m - 1, true, s.st));
-			if (nl == 2) HIPCHK(kry_launch_face(f, send_hi + n, g, dir, m - 2, true, s.st));
+			HIPCHK(kry_launch_face(f, send_hi, g, dir, m - 1, true, st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, send_hi + n, g, dir, m - 2, true, st));
 		}
-		CHK(h->comm.halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (size_t)nl * n, s.st, dir));
+		CHK(h->comm.halo(peer_lo, send_lo, recv_lo, peer_hi, send_hi, recv_hi, (size_t)nl * n, st, dir));
 		if (peer_hi >= 0) {
-			HIPCHK(kry_launch_face(f, recv_hi, g, dir, m + 1, false, s.st));
-			if (nl == 2) HIPCHK(kry_launch_face(f, recv_hi + n, g, dir, m, false, s.st));
+			HIPCHK(kry_launch_face(f, recv_hi, g, dir, m + 1, false, st));
+			if (nl == 2) HIPCHK(kry_launch_face(f, recv_hi + n, g, dir, m, false, st));
 		}
-		if (peer_lo >= 0) HIPCHK(kry_launch_face(f, recv_lo, g, dir, -1, false, s.st));
+		if (peer_lo >= 0) HIPCHK(kry_launch_face(f, recv_lo, g, dir, -1, false, st));
 	}
 	return 0;
 }
@@ -386,7 +392,7 @@ int exchange_halo(kry_solver *h, std::vector<double *> &f)
 {
 	const int ns = (int)h->slabs.size();
 	if (ns == 1 && !h->comm.active()) return 0;
-	if (h->cart) CHK(exchange_xy(h, f[0]));
+	if (h->cart) CHK(exchange_xy(h, f[0], h->slabs[0].st));
 	const size_t bytes = (size_t)h->slabs[0].g.ps * sizeof(double);
 	for (int i = 0; i < ns; ++i) {
 		HIPCHK(hipSetDevice(h->slabs[i].device));
@@ -487,6 +493,56 @@ int exchange_halo_end(kry_solver *h)
 		if (h->comm.active()) prof_end(h, s);
 	}
 	return 0;
+}
+
+// Cartesian split (one sub-domain per process): the whole exchange of an operator output -- x faces,
+// y faces, z planes, in that order, each over the full tangential box -- on the exchange stream.  The
+// main stream does not wait: the kernel that consumes the output runs the tiles that read no exchanged
+// cell meanwhile and waits (halo_wait) before the others (stencil_step).
+int exchange_cart_begin(kry_solver *h, double *f)
+{
+	Slab &s = h->slabs[0];
+	const KryGeo &g = s.g;
+	HIPCHK(hipSetDevice(s.device));
+	HIPCHK(hipEventRecord(s.ev_edge, s.st));
+	HIPCHK(hipStreamWaitEvent(s.st_comm, s.ev_edge, 0));
+	CHK(exchange_xy(h, f, s.st_comm));
+	if (g.has_lo || g.has_hi)
+		CHK(h->comm.halo(g.has_lo ? h->rank_of(h->co[0], h->co[1], h->co[2] - 1) : -1, f + 2L * g.ps, f,
+		                 g.has_hi ? h->rank_of(h->co[0], h->co[1], h->co[2] + 1) : -1, f + (long)g.mz * g.ps,
+		                 f + (long)(g.mz + 2) * g.ps, (size_t)g.ps, s.st_comm));
+	HIPCHK(hipEventRecord(s.ev_halo, s.st_comm));
+	h->halo_pending = true;
+	return 0;
+}
+
+// the main stream goes on only when a pending exchange has filled the ghost cells
+int halo_wait(kry_solver *h)
+{
+	if (!h->halo_pending) return 0;
+	Slab &s = h->slabs[0];
+	HIPCHK(hipSetDevice(s.device));
+	HIPCHK(hipStreamWaitEvent(s.st, s.ev_halo, 0));
+	h->halo_pending = false;
+	return 0;
+}
+
+// The tiles of a general-boundary stencil launch that read no cell an exchange with a neighbour fills
+// (ghost columns -1, mx, mx+1; ghost rows -1, my+1; ghost planes -1, mz+1): a box of tile indices.
+// A tile reads columns 128 tx - 1 .. 128 tx + 129, rows 8 ty - 2 .. 8 ty + 7, planes z0 - 1 .. z1.
+// Returns the number of such tiles (0: none, or no direction has a neighbour).
+int inner_tiles(const KryGeo &g, const KryFused &a, int ib[6])
+{
+	int tx0 = g.nb[0] ? 1 : 0, tx1 = a.ntx - 1;
+	while (tx1 >= tx0 && g.nb[1] && KRY_TXW * tx1 + KRY_TXW + 1 > g.mx - 1) --tx1;
+	int ty0 = g.nb[2] ? 1 : 0, ty1 = a.nty - 1;
+	while (ty1 >= ty0 && g.nb[3] && 8 * ty1 + 7 > g.my) --ty1;
+	int c0 = 0, c1 = a.nchunk - 1;
+	while (c0 <= c1 && g.has_lo && a.zlo + c0 * a.zc - 1 < 0) ++c0;
+	while (c1 >= c0 && g.has_hi && std::min(a.zlo + (c1 + 1) * a.zc, a.zhi + 1) > g.mz) --c1;
+	if (tx1 < tx0 || ty1 < ty0 || c1 < c0) return 0;
+	ib[0] = tx0; ib[1] = tx1; ib[2] = ty0; ib[3] = ty1; ib[4] = c0; ib[5] = c1;
+	return (tx1 - tx0 + 1) * (ty1 - ty0 + 1) * (c1 - c0 + 1);
 }
 
 // 1: the kernel that finishes a reduction also advances the recurrences (one slab in
@@ -626,7 +682,25 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 			KryFused a = args[i];
 			const int nsurf = surf_blocks(s.g);
 			a.red.nblk = a.nblk + nsurf;
-			CHK(launch_fused(h, s, kind, a, 1));
+			int ib[6];
+			const int inner = h->halo_pending ? inner_tiles(s.g, a, ib) : 0;
+			if (inner > 0 && inner < a.nblk) {
+				// the ghost cells of an operand are still on their way: the tiles that read none of them
+				// first, the others when the exchange is done (one reduction over both launches)
+				const int all = a.nblk;
+				h->overlapped_exchanges += 1;
+				for (int k = 0; k < 6; ++k) a.ib[k] = ib[k];
+				a.ch_sel = 3;
+				a.nblk = inner;
+				CHK(launch_fused(h, s, kind, a, 1));
+				CHK(halo_wait(h));
+				a.ch_sel = 4;
+				a.nblk = all - inner;
+				CHK(launch_fused(h, s, kind, a, 0));
+			} else {
+				CHK(halo_wait(h));
+				CHK(launch_fused(h, s, kind, a, 1));
+			}
 			HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));   // the z faces follow in k_surf
 		}
 		// planes 1 and mz-1, the ones the z neighbours need, are final once the x and y faces
@@ -644,9 +718,11 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 			prof_end(h, s);
 		}
 		if (beside) CHK(exchange_halo_end(h));
+		else if (multi && h->cart && h->overlap && !h->comm.halo_blocks_host()) CHK(exchange_cart_begin(h, outs[0]));
 		else if (multi) CHK(exchange_halo(h, outs));
 		return 0;
 	}
+	CHK(halo_wait(h));
 	// the neighbours need planes 1 and mz-1: chunk 0 and the chunk holding plane mz-1
 	// (the last one, or the one before it when the last chunk is plane mz alone)
 	std::vector<int> n_edge(ns);
@@ -704,6 +780,7 @@ int fused_pass_general(kry_solver *h, int it)
 	for (int k = 0; k <= L; ++k) cr[k] = cu[k] = (k < L) ? p : 0;
 	auto flip = [&](int *c, int k) { c[k] = 1 - p; };
 	auto for_slabs = [&](auto &&fn) -> int {
+		CHK(halo_wait(h));      // the streaming kernels read and update ghost cells too
 		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
 		return 0;
 	};
@@ -810,6 +887,7 @@ int fused_pass(kry_solver *h, int it)
 	const int nk = (L == 1) ? 3 : 6;
 	auto rev_of = [&](int k, bool b_kernel) { return h->alt ? ((it * nk + k) & 1) : (b_kernel ? 1 : 0); };
 	auto for_slabs = [&](auto &&fn) -> int {
+		CHK(halo_wait(h));      // the streaming kernels read and update ghost cells too
 		for (size_t i = 0; i < h->slabs.size(); ++i) CHK(fn(h->slabs[i], (int)i));
 		return 0;
 	};
@@ -1388,6 +1466,7 @@ int run_iterations(kry_solver *h, int n_outer)
 			if (n_outer > 0) left -= 1;
 		}
 	}
+	CHK(halo_wait(h));
 	HIPCHK(hipSetDevice(s0.device));
 	HIPCHK(hipEventRecord(e1, s0.st));
 	CHK(sync_all(h));
@@ -1454,6 +1533,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	double t0 = now_ms();
 	drop_graph(h);
 	h->staged_fields = 0;
+	h->overlapped_exchanges = 0;
 	h->pending_stage_ms = 0;
 	h->var = var;
 	h->offd = var && offd;
@@ -2101,6 +2181,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	}
 	o->rccl_ranks = h->comm.rccl_ranks();
 	o->staged_fields = h->staged_fields;
+	o->overlapped_exchanges = h->overlapped_exchanges;
 	o->tile_rows = h->gen ? 8 : h->ty;
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;

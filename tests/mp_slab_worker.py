@@ -99,7 +99,7 @@ def main():
         stats = s.stats()
         hist = s.history()
     np.savez(os.path.join(outdir, "r%d.npz" % rank), phi=phi, hist=hist, status=st, iters=stats.iterations,
-             fused=stats.fused, norm_rhs=stats.norm_rhs)
+             fused=stats.fused, norm_rhs=stats.norm_rhs, overlapped=stats.overlapped_exchanges)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,5 +1,3 @@
 set -e
-tools/r3_profile_const256.sh r3
-tools/collect_profiles.sh r3_var var
-tools/collect_profiles.sh r3_var_l1 var --ell 1
+timeout -k 10 900 python -u -m pytest tests/test_gpu_multiproc.py -x -q --timeout 300 --timeout-method thread -k "mapped_memory_exchange_reproduces or cartesian" > gpurun_out/r3p_tests.log 2>&1
 echo ok
