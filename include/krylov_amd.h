@@ -106,6 +106,8 @@ typedef struct kry_stats {
 	                            full solve, only the replaced ones after kry_update_* + kry_resolve */
 	int    overlapped_exchanges; /* Cartesian split: stencil launches since the last load that ran their inner tiles
 	                            while the ghost cells of their input were still being exchanged */
+	int    slab_link;        /* 1: the slabs of this process exchange through each other's device memory
+	                            (kry_slab_link_note), 0: by copies and events, or there is one slab */
 } kry_stats;
 
 typedef struct kry_solver *kry_handle;
@@ -242,6 +244,20 @@ int kry_resolve(kry_handle h, double *phi, int debug);
 int kry_set_profile(kry_handle h, int on);
 
 int kry_get_stats(kry_handle h, kry_stats *out);
+
+/* Several slabs in ONE process (slab_count > 1, no other process): the analogue of the reference's
+ * exchange between MPI ranks (BICGStab3D/BoundaryHandler.C:1633-1677, BICGStab3D/Krylov.C:239-240)
+ * inside a process that drives several GPUs.  When every slab has a device of its own and the
+ * devices can address each other's memory, the slabs are linked like the processes of
+ * kry_mail_connect: the kernel that finishes a reduction adds the slabs' sums through mailboxes
+ * in the peers' memory, a kernel of the sender stores the interface planes into landing slots of
+ * the neighbour -- per dot product and per operator output no copy, no event between slabs and no
+ * extra kernel is queued, and the sums are added in slab order either way (same bits).
+ * kry_create sets the link up and tries it once (2 s at most); if that fails the slabs exchange
+ * by device-to-device copies ordered by events.  Environment: KRY_SLAB_LINK=0 keeps the copies,
+ * =1 also links two slabs that share a device.  kry_stats.slab_link tells which route is in use,
+ * this function why ("on", or the reason it is off); the string lives as long as the handle. */
+const char *kry_slab_link_note(kry_handle h);
 /* `norm` of every outer iteration (solveLin_BICGStab.C:464); returns the count. */
 int kry_get_history(kry_handle h, double *norms, int cap);
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     "kry_comm_selftest", "kry_mail_export", "kry_mail_connect", "kry_mail_enable", "kry_solve_const",
     "kry_solve_var", "kry_load_const", "kry_load_var", "kry_iterate", "kry_fetch_phi", "kry_fetch_residual",
     "kry_update_rhs", "kry_update_phi", "kry_update_lambda", "kry_reset", "kry_resolve",
-    "kry_set_profile", "kry_get_stats", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
+    "kry_set_profile", "kry_get_stats", "kry_slab_link_note", "kry_get_history", "kry_get_step_times", "kry_op_do_bcs", "kry_op_spmv_const", "kry_op_spmv_var",
     "kry_op_dot", "kry_op_l2norm", "kry_op_dot_static", "kry_status_string", "kry_last_error",
 ]
 
@@ -73,6 +73,7 @@ class KryStats(C.Structure):
         ("rccl_ranks", C.c_int),
         ("staged_fields", C.c_int),
         ("overlapped_exchanges", C.c_int),
+        ("slab_link", C.c_int),
     ]
 
 
@@ -164,6 +165,8 @@ def lib():
     L.kry_op_l2norm.argtypes = [vp, _dp, P(cd)]
     L.kry_op_dot_static.restype = ci
     L.kry_op_dot_static.argtypes = [ci, vp, vp, C.c_int * 3, ci, vp, vp]
+    L.kry_slab_link_note.restype = C.c_char_p
+    L.kry_slab_link_note.argtypes = [vp]
     L.kry_status_string.restype = C.c_char_p
     L.kry_status_string.argtypes = [ci]
     L.kry_last_error.restype = C.c_char_p
@@ -342,6 +345,9 @@ class Solver:
     def fetch_residual(self, r0):
         return _check(lib().kry_fetch_residual(self._h, r0), "kry_fetch_residual")
 
+    def slab_link_note(self):
+        return lib().kry_slab_link_note(self._h).decode(errors="replace")
+
     def stats(self):
         s = KryStats()
         _check(lib().kry_get_stats(self._h, C.byref(s)), "kry_get_stats")
@@ -398,7 +404,9 @@ def solve_problem(p, L=2, eps=1e-6, max_outer=0, flags=0, nslabs_local=1, device
             st = s.solve_const(phi, p.rhs, p.lam, p.Dc, debug)
         stats = s.stats()
         hist = s.history()
+        note = s.slab_link_note()
     return dict(status=st, phi=phi, history=hist, iters=stats.iterations, norm_rhs=stats.norm_rhs,
+                slab_link=int(stats.slab_link), slab_link_note=note,
                 norm_init=stats.norm_init, norm_final=stats.norm_final, fused=bool(stats.fused), path=int(stats.fused),
                 solve_ms=stats.solve_ms, stage_ms=stats.stage_ms,
                 order=(stats.tile_rows, stats.chunk_planes, stats.stream_blocks))

@@ -111,6 +111,9 @@ hipError_t kry_launch_halo_push(const double *send_lo, double *slot_lo, unsigned
 hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned long long *flag_lo, double *recv_hi,
                                 const double *slot_hi, unsigned long long *flag_hi, size_t count, unsigned long long seq,
                                 long long timeout, KryState *S, hipStream_t st);
+// a one-block grid reduction of `v` with r.nblk == 1: S->sums[0] receives v, or the sum of the
+// ranks' / slabs' values when S->mail is set
+hipError_t kry_launch_link_probe(const KryRed &r, double v, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,

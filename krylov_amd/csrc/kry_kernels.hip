@@ -1616,6 +1616,14 @@ __global__ __launch_bounds__(NT) void k_halo_pull(KryHaloSide lo, KryHaloSide hi
 	if (hi.src) halo_copy(hi, count);
 }
 
+// One value per slab or rank, all-reduced the way the reducing kernels do it (through the
+// mailboxes when S->mail is set): a check that a freshly made link carries data.
+__global__ __launch_bounds__(NT) void k_link_probe(KryRed r, double v)
+{
+	double acc[1] = {threadIdx.x == 0 ? v : 0.};
+	reduce_and_finalize<1>(acc, r);
+}
+
 // dst = a - b (Krylov.C:259)
 __global__ __launch_bounds__(NT) void g_sub(double *dst, const double *x, const double *y, long n2)
 {
@@ -2015,6 +2023,12 @@ hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned
 	KryHaloSide lo = {slot_lo, recv_lo, flag_lo}, hi = {slot_hi, recv_hi, flag_hi};
 	const int nb = (int)std::max<size_t>(1, std::min<size_t>((count / 2 + NT - 1) / NT, 128));
 	hipLaunchKernelGGL(k_halo_pull, dim3(nb), dim3(NT), 0, st, lo, hi, count, seq, timeout, S);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_link_probe(const KryRed &r, double v, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_link_probe, dim3(1), dim3(NT), 0, st, r, v);
 	return hipGetLastError();
 }
 

@@ -91,6 +91,7 @@ struct Slab {
 	std::vector<void *> mail_mapped;   // peers' mailboxes as opened here
 	bool mail_on = false;
 	size_t link_cap = 0;               // doubles per landing slot of the ghost-plane exchange
+	KryComm link;                      // link to the other slabs of THIS process (kry_solver::slab_link)
 	std::vector<Field *> all;
 };
 
@@ -129,6 +130,13 @@ struct kry_solver {
 	int it_base = 0;           // outer iterations completed (mirrors S->iter)
 	int status = 0;
 	bool done = false;
+	// Several slabs in this process and no other process: the slabs exchange like the processes of a
+	// split do through mapped memory -- every slab owns a mailbox and landing slots in uncached memory
+	// of its device, which the other slabs' kernels address directly (peer access), the kernel that
+	// finishes a reduction adds the slabs' sums itself, and the ghost planes are pushed by a kernel of
+	// the sender.  No copies, cross-slab event waits or extra kernels are queued per dot product.
+	bool slab_link = false;
+	std::string slab_link_note = "one slab";   // why the link is on or off
 	bool halo_pending = false;  // an exchange of an operator output is running on the exchange stream (Cartesian split)
 	bool alt = true;            // every kernel of a pass takes its work in the opposite order of the one before it
 	bool tail_bc_done = false;  // the post-loop do_BCs(phi) of a constant-coefficient solve has been applied
@@ -299,6 +307,7 @@ int reduce_sums(kry_solver *h, int phase)
 	const int ns = (int)h->slabs.size();
 	const bool remote = h->comm.active();
 	if (ns == 1 && (!remote || h->slabs[0].mail_on)) return 0;   // the kernel's last block did it all
+	if (h->slab_link) return 0;                                   // ... over the slabs' mailboxes
 	Slab &s0 = h->slabs[0];
 	// The total is formed in a buffer of its own (the first slab's `gather` tail):
 	// S->sums of a slab is rewritten by that slab's next reducing kernel, which
@@ -388,11 +397,31 @@ int exchange_xy(kry_solver *h, double *f, hipStream_t st)
 	return 0;
 }
 
+// Ghost planes of slab i through the link between the slabs of this process: its planes 1 and mz-1
+// are stored into the neighbours' landing slots, its own slots are awaited and copied into the
+// ghost planes (two kernels on `st`; slab numbers play the part of ranks).
+int link_halo(kry_solver *h, int i, double *b, hipStream_t st)
+{
+	Slab &s = h->slabs[i];
+	const KryGeo &g = s.g;
+	HIPCHK(hipSetDevice(s.device));
+	if (s.link.halo(i > 0 ? i - 1 : -1, b + 2L * g.ps, b, i + 1 < (int)h->slabs.size() ? i + 1 : -1,
+	                b + (long)g.mz * g.ps, b + (long)(g.mz + 2) * g.ps, (size_t)g.ps, st) < 0) {
+		set_err("%s", KryComm::last_error());
+		return KRY_ERR_COMM;
+	}
+	return 0;
+}
+
 int exchange_halo(kry_solver *h, std::vector<double *> &f)
 {
 	const int ns = (int)h->slabs.size();
 	if (ns == 1 && !h->comm.active()) return 0;
 	if (h->cart) CHK(exchange_xy(h, f[0], h->slabs[0].st));
+	if (h->slab_link) {
+		for (int i = 0; i < ns; ++i) CHK(link_halo(h, i, f[i], h->slabs[i].st));
+		return 0;
+	}
 	const size_t bytes = (size_t)h->slabs[0].g.ps * sizeof(double);
 	for (int i = 0; i < ns; ++i) {
 		HIPCHK(hipSetDevice(h->slabs[i].device));
@@ -457,6 +486,12 @@ int exchange_halo_begin(kry_solver *h, std::vector<double *> &f)
 		const KryGeo &g = s.g;
 		HIPCHK(hipSetDevice(s.device));
 		HIPCHK(hipStreamWaitEvent(s.st_comm, s.ev_edge, 0));
+		if (h->slab_link) {
+			// (the kernels wait for the neighbours' planes themselves)
+			CHK(link_halo(h, i, f[i], s.st_comm));
+			HIPCHK(hipEventRecord(s.ev_halo, s.st_comm));
+			continue;
+		}
 		if (i > 0) {         // ghost -1 <- lower slab's plane mz-1
 			HIPCHK(hipStreamWaitEvent(s.st_comm, h->slabs[i - 1].ev_edge, 0));
 			HIPCHK(hipMemcpyAsync(f[i], f[i - 1] + (long)g.mz * g.ps, bytes, hipMemcpyDeviceToDevice, s.st_comm));
@@ -488,8 +523,9 @@ int exchange_halo_end(kry_solver *h)
 		// (timed: how long the main stream sits idle until the planes are there)
 		if (h->comm.active()) prof_begin(h, s, 9);
 		HIPCHK(hipStreamWaitEvent(s.st, s.ev_halo, 0));
-		if (i > 0) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i - 1].ev_halo, 0));
-		if (i + 1 < ns) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i + 1].ev_halo, 0));
+		// (through the link a slab's planes are read by its own kernel only)
+		if (i > 0 && !h->slab_link) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i - 1].ev_halo, 0));
+		if (i + 1 < ns && !h->slab_link) HIPCHK(hipStreamWaitEvent(s.st, h->slabs[i + 1].ev_halo, 0));
 		if (h->comm.active()) prof_end(h, s);
 	}
 	return 0;
@@ -549,6 +585,7 @@ int inner_tiles(const KryGeo &g, const KryFused &a, int ib[6])
 // this process, and either no other process or the mailbox all-reduce between them)
 int local_scalars(const kry_solver *h)
 {
+	if (h->slab_link) return 1;
 	return (h->slabs.size() == 1 && (!h->comm.active() || h->slabs[0].mail_on)) ? 1 : 0;
 }
 
@@ -1287,7 +1324,6 @@ int prologue(kry_solver *h)
 		init.max_outer = h->d.max_outer;
 		init.L = h->L;
 		init.local_scalars = local_scalars(h);
-			init.mail = h->slabs[0].mail_on ? h->slabs[0].mail_dev : nullptr;
 		init.norm_init = std::sqrt(ss);
 		init.norm = 1.e99;
 		if (init.norm_init < h->d.eps * h->norm_rhs) {
@@ -1306,6 +1342,7 @@ int prologue(kry_solver *h)
 			Slab &s = h->slabs[i];
 			HIPCHK(hipSetDevice(s.device));
 			HIPCHK(hipMemcpyAsync(rt[i], r0[i], (size_t)s.g.n * sizeof(double), hipMemcpyDeviceToDevice, s.st));
+			init.mail = s.mail_on ? s.mail_dev : nullptr;
 			memcpy(s.Sh, &init, offsetof(KryState, hist));
 			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
 			HIPCHK(hipStreamSynchronize(s.st));
@@ -1321,7 +1358,7 @@ int prologue(kry_solver *h)
 			init.max_outer = h->d.max_outer;
 			init.L = h->L;
 			init.local_scalars = local_scalars(h);
-			init.mail = h->slabs[0].mail_on ? h->slabs[0].mail_dev : nullptr;
+			init.mail = s.mail_on ? s.mail_dev : nullptr;
 			memcpy(s.Sh, &init, offsetof(KryState, hist));
 			HIPCHK(hipMemcpyAsync(s.S, s.Sh, offsetof(KryState, hist), hipMemcpyHostToDevice, s.st));
 			HIPCHK(hipStreamSynchronize(s.st));
@@ -1585,6 +1622,180 @@ int finish_solve(kry_solver *h, double *phi)
 	return 0;
 }
 
+static size_t mail_bytes(int nranks) { return sizeof(double) * KRY_MAIL_SLOT * (1 + 2 * (size_t)nranks); }
+
+long long mail_timeout_ticks(int device, long fallback_ms)
+{
+	int khz = 0;
+	if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
+	const char *e = getenv("KRY_MAIL_TIMEOUT_MS");
+	const long ms = e ? std::max(1L, atol(e)) : fallback_ms;
+	return (long long)khz * ms;
+}
+
+// (Re)writes the kernels' description of slab i's mailbox and the link's timeout.
+int link_describe(kry_solver *h, int i, long long timeout)
+{
+	const int ns = (int)h->slabs.size();
+	Slab &s = h->slabs[i];
+	KryMail m;
+	memset(&m, 0, sizeof m);
+	m.rank = i;
+	m.nranks = ns;
+	m.timeout = timeout;
+	m.box = s.mail_box;
+	std::vector<char *> bases(ns);
+	for (int r = 0; r < ns; ++r) {
+		m.peer[r] = h->slabs[r].mail_box;
+		bases[r] = (char *)h->slabs[r].mail_box;
+	}
+	HIPCHK(hipSetDevice(s.device));
+	if (!s.mail_dev) HIPCHK(hipMalloc((void **)&s.mail_dev, sizeof m));
+	HIPCHK(hipMemcpy(s.mail_dev, &m, sizeof m, hipMemcpyHostToDevice));
+	if (s.link.set_link(i, (char *)s.mail_box, bases, s.link_cap, timeout, s.S) < 0) {
+		set_err("%s", KryComm::last_error());
+		return KRY_ERR_HIP;
+	}
+	return 0;
+}
+
+int link_switch(kry_solver *h, bool on)
+{
+	h->slab_link = on;
+	for (Slab &s : h->slabs) {
+		s.mail_on = on;
+		s.link.link_planes(on);
+		const int ls = local_scalars(h);
+		const KryMail *mp = on ? s.mail_dev : nullptr;
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipMemcpy(&s.S->local_scalars, &ls, sizeof ls, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(&s.S->mail, &mp, sizeof mp, hipMemcpyHostToDevice));
+	}
+	return 0;
+}
+
+// One all-reduce and one ghost-plane exchange of known numbers through a fresh link, with a short
+// time-out: 0 when every slab received what it should.
+int link_probe(kry_solver *h)
+{
+	const int ns = (int)h->slabs.size();
+	const int cnt = 16, send = 64, rlo = 128, rhi = 192;   // offsets into the slab's partial-sum array
+	std::vector<double> host(256);
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		for (int k = 0; k < 256; ++k) host[k] = -1.;
+		for (int k = 0; k < cnt; ++k) host[send + k] = 100. * (i + 1) + k;
+		HIPCHK(hipMemcpy(s.partial, host.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+	}
+	// every slab's kernels are queued before any is waited for: they wait for each other
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		if (s.link.halo(i > 0 ? i - 1 : -1, s.partial + send, s.partial + rlo, i + 1 < ns ? i + 1 : -1, s.partial + send,
+		                s.partial + rhi, (size_t)cnt, s.st_comm) < 0) {
+			set_err("%s", KryComm::last_error());
+			return KRY_ERR_COMM;
+		}
+	}
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipStreamSynchronize(s.st_comm));
+		HIPCHK(hipMemcpy(host.data(), s.partial, 256 * sizeof(double), hipMemcpyDeviceToHost));
+		for (int k = 0; k < cnt; ++k) {
+			const bool ok_lo = i == 0 || host[rlo + k] == 100. * i + k;
+			const bool ok_hi = i + 1 == ns || host[rhi + k] == 100. * (i + 2) + k;
+			if (!ok_lo || !ok_hi) { set_err("slab %d did not receive its neighbours' planes", i); return KRY_ERR_COMM; }
+		}
+	}
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(kry_launch_link_probe(make_red(s, 1, PH_NONE), (double)(i + 1), s.st));
+	}
+	for (int i = 0; i < ns; ++i) {
+		Slab &s = h->slabs[i];
+		HIPCHK(hipSetDevice(s.device));
+		HIPCHK(hipMemcpyAsync(s.Sh, s.S, offsetof(KryState, hist), hipMemcpyDeviceToHost, s.st));
+		HIPCHK(hipStreamSynchronize(s.st));
+		if (s.Sh->status != 0 || s.Sh->sums[0] != 0.5 * ns * (ns + 1)) {
+			set_err("slab %d: the sums of the other slabs did not arrive", i);
+			return KRY_ERR_COMM;
+		}
+	}
+	return 0;
+}
+
+// Decides whether the slabs of this process exchange through the link, sets it up and tries it.
+// Kernels of different slabs then wait for each other, so they must be able to run side by side:
+// by default the link is made when every slab has a device of its own and all those devices can
+// address each other; KRY_SLAB_LINK=1 also allows two slabs on one device (their four streams get
+// the device's four hardware queues), KRY_SLAB_LINK=0 keeps copies and events.  Never fatal: when
+// anything fails the slabs exchange by copies as before and kry_stats.slab_link stays 0.
+int link_local_slabs(kry_solver *h)
+{
+	const int ns = (int)h->slabs.size();
+	auto off = [&](const char *why) { h->slab_link = false; h->slab_link_note = why; return 0; };
+	if (ns < 2) return off("one slab");
+	if (h->cart || h->d.nslabs != ns) return off("other processes hold sub-domains too");
+	const char *e = getenv("KRY_SLAB_LINK");
+	const int want = e ? atoi(e) : -1;
+	if (want == 0) return off("KRY_SLAB_LINK=0");
+	int most = 0;
+	for (int i = 0; i < ns; ++i) {
+		int same = 0;
+		for (int j = 0; j < ns; ++j) same += h->slabs[j].device == h->slabs[i].device;
+		most = std::max(most, same);
+	}
+	if (most > 2 || (most > 1 && want != 1)) return off("several slabs share a device");
+	for (int i = 0; i < ns; ++i)
+		for (int j = 0; j < ns; ++j) {
+			const int a = h->slabs[i].device, b = h->slabs[j].device;
+			if (a == b) continue;
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+				(void)hipGetLastError();
+				return off("a device cannot address another one's memory");
+			}
+			hipSetDevice(a);
+			hipDeviceEnablePeerAccess(b, 0);      // (already enabled: an error to forget)
+			(void)hipGetLastError();
+		}
+	auto undo = [&](const char *why) {
+		link_switch(h, false);
+		for (Slab &s : h->slabs) {
+			hipSetDevice(s.device);
+			hipStreamSynchronize(s.st);
+			hipStreamSynchronize(s.st_comm);
+			s.link.destroy();
+			if (s.mail_dev) hipFree(s.mail_dev);
+			if (s.mail_box) hipFree(s.mail_box);
+			s.mail_dev = nullptr;
+			s.mail_box = nullptr;
+		}
+		(void)hipGetLastError();
+		return off(why);
+	};
+	for (Slab &s : h->slabs) {
+		if (hipSetDevice(s.device) != hipSuccess) return undo("hipSetDevice failed");
+		s.link_cap = (size_t)s.g.ps;
+		const size_t bytes = std::max(KryComm::link_bytes(s.link_cap), mail_bytes(ns));
+		// uncached: what another device stores is seen by a kernel already running here
+		if (hipExtMallocWithFlags((void **)&s.mail_box, bytes, hipDeviceMallocUncached) != hipSuccess ||
+		    hipMemset(s.mail_box, 0, bytes) != hipSuccess)
+			return undo("no memory for the mailboxes");
+	}
+	for (int i = 0; i < ns; ++i)
+		if (link_describe(h, i, mail_timeout_ticks(h->slabs[i].device, 30000L) / 15) < 0) return undo("set-up failed");   // 2 s for the trial
+	if (link_switch(h, true) < 0) return undo("set-up failed");
+	if (link_probe(h) < 0) return undo("the trial exchange failed");
+	for (int i = 0; i < ns; ++i)
+		if (link_describe(h, i, mail_timeout_ticks(h->slabs[i].device, 30000L)) < 0) return undo("set-up failed");
+	h->slab_link_note = "on";
+	return 0;
+}
+
 } // namespace
 
 // A process may hold a second copy of the HIP runtime (a Python package that bundles
@@ -1771,6 +1982,7 @@ kry_handle kry_create(const kry_desc *d, int *status)
 		const int nch = (nz + h->zc - 1) / h->zc;
 		h->zc = (nz + nch - 1) / nch;
 	}
+	if (st >= 0) st = link_local_slabs(h);
 	if (st < 0) {
 		kry_destroy(h);
 		return fail(st);
@@ -1791,6 +2003,7 @@ void kry_destroy(kry_handle h)
 	h->comm.destroy();
 	for (Slab &s : h->slabs) {
 		hipSetDevice(s.device);
+		s.link.destroy();
 		free_fields(s);
 		if (s.S) hipFree(s.S);
 		if (s.Sh) hipHostFree(s.Sh);
@@ -1892,8 +2105,6 @@ int kry_comm_init_host_callbacks(kry_handle h, int rank, int nranks, kry_allredu
 	if (st < 0) set_err("%s", KryComm::last_error());
 	return st;
 }
-
-static size_t mail_bytes(int nranks) { return sizeof(double) * KRY_MAIL_SLOT * (1 + 2 * (size_t)nranks); }
 
 int kry_mail_export(kry_handle h, void *handle)
 {
@@ -2182,11 +2393,14 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	o->rccl_ranks = h->comm.rccl_ranks();
 	o->staged_fields = h->staged_fields;
 	o->overlapped_exchanges = h->overlapped_exchanges;
+	o->slab_link = h->slab_link ? 1 : 0;
 	o->tile_rows = h->gen ? 8 : h->ty;
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;
 	return 0;
 }
+
+const char *kry_slab_link_note(kry_handle h) { return h ? h->slab_link_note.c_str() : ""; }
 
 int kry_get_history(kry_handle h, double *norms, int cap)
 {

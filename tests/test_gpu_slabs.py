@@ -151,3 +151,47 @@ def test_sixteen_slabs_on_one_device_with_overlapped_exchange(orc, monkeypatch):
         assert np.array_equal(r["history"], runs[0]["history"])
         assert np.max(np.abs(r["history"] - one["history"])) <= 1e-10 * one["norm_rhs"]
         assert rel_l2(points(r["phi"]), points(one["phi"])) <= 1e-10
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("kind,L,flags", [("var", 1, 0), ("var", 2, 0), ("var", 3, 0), ("const", 2, 0),
+                                          ("mixed", 2, 0), ("mixed", 1, 0), ("var", 2, capi.KRY_FORCE_GENERIC)])
+def test_slabs_linked_through_device_memory_reproduce_the_copies(orc, monkeypatch, kind, L, flags, overlap):
+    """Two slabs of one process linked through each other's device memory (mailbox all-reduce by the
+    reducing kernels, ghost planes pushed by the sender's kernel) against the same slabs exchanging by
+    copies and events: same history, same solution, bit for bit (the sums are added in slab order on
+    both routes).  Here both slabs share the one device, which KRY_SLAB_LINK=1 permits; with a device
+    per slab the link is the default."""
+    monkeypatch.setenv("KRY_ZC", "4")            # short chunks: the stencil launches are split around the exchange
+    monkeypatch.setenv("KRY_OVERLAP", overlap)
+    monkeypatch.setenv("KRY_MAIL_TIMEOUT_MS", "5000")
+    if kind == "const":
+        p = P.reference_test1(32)
+        p.rhs = P.interior_only(np.random.default_rng(5).uniform(-1, 1, p.rhs.shape))
+    else:
+        p = P.smooth_var((40, 24, 32), bc=(0, 1, 1, 0, 1, 1)) if kind == "mixed" else P.smooth_var(32)
+        p.rhs = np.random.default_rng(6).uniform(-1, 1, p.rhs.shape)
+    runs = {}
+    for link in ("0", "1"):
+        monkeypatch.setenv("KRY_SLAB_LINK", link)
+        runs[link] = capi.solve_problem(p, L=L, eps=1e-30, max_outer=6, nslabs_local=2, devices=(0,), flags=flags)
+    a, b = runs["0"], runs["1"]
+    assert a["slab_link"] == 0 and a["slab_link_note"] == "KRY_SLAB_LINK=0"
+    assert b["slab_link"] == 1 and b["slab_link_note"] == "on", b["slab_link_note"]
+    assert a["iters"] == b["iters"] == 6 and a["status"] == b["status"]
+    assert np.array_equal(a["history"], b["history"])
+    assert np.array_equal(a["phi"], b["phi"])
+
+
+def test_slab_link_is_not_made_where_kernels_could_not_run_side_by_side(orc, monkeypatch):
+    """Linked slabs wait for each other inside kernels.  Two slabs on one device are linked only on
+    request, more than two never (their streams would share hardware queues): the copies stay."""
+    p = P.smooth_var(32)
+    monkeypatch.delenv("KRY_SLAB_LINK", raising=False)
+    r = capi.solve_problem(p, L=2, eps=1e-30, max_outer=2, nslabs_local=2, devices=(0,))
+    assert r["slab_link"] == 0 and "share a device" in r["slab_link_note"]
+    monkeypatch.setenv("KRY_SLAB_LINK", "1")
+    r = capi.solve_problem(p, L=2, eps=1e-30, max_outer=2, nslabs_local=4, devices=(0,))
+    assert r["slab_link"] == 0 and "share a device" in r["slab_link_note"] and r["iters"] == 2
+    r = capi.solve_problem(p, L=2, eps=1e-30, max_outer=2)
+    assert r["slab_link"] == 0 and r["slab_link_note"] == "one slab"
