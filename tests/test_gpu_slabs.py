@@ -153,32 +153,52 @@ def test_sixteen_slabs_on_one_device_with_overlapped_exchange(orc, monkeypatch):
         assert rel_l2(points(r["phi"]), points(one["phi"])) <= 1e-10
 
 
+LINK_WORKER = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from krylov_amd import capi, problems as P
+kind, L, flags, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+if kind == "const":
+    p = P.reference_test1(32)
+    p.rhs = P.interior_only(np.random.default_rng(5).uniform(-1, 1, p.rhs.shape))
+else:
+    p = P.smooth_var((40, 24, 32), bc=(0, 1, 1, 0, 1, 1)) if kind == "mixed" else P.smooth_var(32)
+    p.rhs = np.random.default_rng(6).uniform(-1, 1, p.rhs.shape)
+r = capi.solve_problem(p, L=L, eps=1e-30, max_outer=6, nslabs_local=2, devices=(0,), flags=flags)
+np.savez(out, phi=r["phi"], history=r["history"], iters=r["iters"], status=r["status"], slab_link=r["slab_link"])
+print(r["slab_link_note"])
+"""
+
+
 @pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("kind,L,flags", [("var", 1, 0), ("var", 2, 0), ("var", 3, 0), ("const", 2, 0),
                                           ("mixed", 2, 0), ("mixed", 1, 0), ("var", 2, capi.KRY_FORCE_GENERIC)])
-def test_slabs_linked_through_device_memory_reproduce_the_copies(orc, monkeypatch, kind, L, flags, overlap):
+def test_slabs_linked_through_device_memory_reproduce_the_copies(tmp_path, kind, L, flags, overlap):
     """Two slabs of one process linked through each other's device memory (mailbox all-reduce by the
     reducing kernels, ghost planes pushed by the sender's kernel) against the same slabs exchanging by
     copies and events: same history, same solution, bit for bit (the sums are added in slab order on
     both routes).  Here both slabs share the one device, which KRY_SLAB_LINK=1 permits; with a device
-    per slab the link is the default."""
-    monkeypatch.setenv("KRY_ZC", "4")            # short chunks: the stencil launches are split around the exchange
-    monkeypatch.setenv("KRY_OVERLAP", overlap)
-    monkeypatch.setenv("KRY_MAIL_TIMEOUT_MS", "5000")
-    if kind == "const":
-        p = P.reference_test1(32)
-        p.rhs = P.interior_only(np.random.default_rng(5).uniform(-1, 1, p.rhs.shape))
-    else:
-        p = P.smooth_var((40, 24, 32), bc=(0, 1, 1, 0, 1, 1)) if kind == "mixed" else P.smooth_var(32)
-        p.rhs = np.random.default_rng(6).uniform(-1, 1, p.rhs.shape)
+    per slab the link is the default.  Linked kernels of the two slabs wait for each other, so their
+    four streams must sit on four different hardware queues of the device; a process hands its queues
+    out in turn, which a fresh process makes certain -- hence one process per solve here.  (Where the
+    streams do share a queue the trial exchange at creation times out and the copies are used.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
     for link in ("0", "1"):
-        monkeypatch.setenv("KRY_SLAB_LINK", link)
-        runs[link] = capi.solve_problem(p, L=L, eps=1e-30, max_outer=6, nslabs_local=2, devices=(0,), flags=flags)
-    a, b = runs["0"], runs["1"]
-    assert a["slab_link"] == 0 and a["slab_link_note"] == "KRY_SLAB_LINK=0"
-    assert b["slab_link"] == 1 and b["slab_link_note"] == "on", b["slab_link_note"]
-    assert a["iters"] == b["iters"] == 6 and a["status"] == b["status"]
+        out = str(tmp_path / ("link%s.npz" % link))
+        env = dict(os.environ, KRY_ZC="4", KRY_OVERLAP=overlap, KRY_MAIL_TIMEOUT_MS="5000", KRY_SLAB_LINK=link)
+        res = subprocess.run([sys.executable, "-c", LINK_WORKER % {"root": root}, kind, str(L), str(flags), out], env=env,
+                             capture_output=True, text=True, timeout=110)
+        assert res.returncode == 0, res.stderr[-2000:]
+        runs[link] = (np.load(out), res.stdout.strip().splitlines()[-1])
+    (a, note_a), (b, note_b) = runs["0"], runs["1"]
+    assert int(a["slab_link"]) == 0 and note_a == "KRY_SLAB_LINK=0"
+    assert int(b["slab_link"]) == 1 and note_b == "on", note_b
+    assert int(a["iters"]) == int(b["iters"]) == 6 and int(a["status"]) == int(b["status"])
     assert np.array_equal(a["history"], b["history"])
     assert np.array_equal(a["phi"], b["phi"])
 
