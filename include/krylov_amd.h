@@ -92,8 +92,9 @@ typedef struct kry_stats {
 	double kernel_ms[8];     /* HIP-event time per fused kernel kind, summed over calls */
 	int    kernel_calls[8];
 	int    tile_rows;        /* launch geometry, which fixes the summation order of the dots: */
-	int    chunk_planes;     /*   rows per fused tile, planes per fused chunk,               */
-	int    stream_blocks;    /*   grid target of the streaming kernels                        */
+	int    chunk_planes;     /*   rows per fused tile (negative: general-boundary tiles that  */
+	int    stream_blocks;    /*   start at grid row 0 instead of -1), planes per fused chunk, */
+	                         /*   grid target of the streaming kernels                        */
 	double enqueue_ms;       /* host time spent queueing kernels and transfers of the passes  */
 	/* Exchange between the sub-domains of a split, device time on this process's first slab since
 	 * the last load: [0] the all-reduces of the dot products, [1] waiting for ghost planes.

@@ -58,6 +58,8 @@ struct KryFused {
 	int blk_off;             // offset of this launch's blocks in the partial-sum array
 	int rev;                 // 1: the blocks take the tiles in reverse order (every kernel starts where the one
 	                         // before it ended, on data the memory-side cache still holds)
+	int y_off;               // general boundaries: tile row 0 starts at grid row -y_off (1: the tiles cover the rows
+	                         // -1 .. my+1; 0: they cover 0 .. 8*nty-1 and kry_launch_bcs_rows updates the rest)
 };
 
 // pointwise statements of BiCG step jj > 0 of the general-l pass: the current copies of r_0..r_jj-1 and u_0..u_jj
@@ -116,6 +118,9 @@ hipError_t kry_launch_halo_pull(double *recv_lo, const double *slot_lo, unsigned
 hipError_t kry_launch_link_probe(const KryRed &r, double v, hipStream_t st);
 hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n, hipStream_t st);
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
+// x and y faces of the output a.O of a general-boundary stencil kernel launched with y_off == 0, after the
+// vector update of the rows its tiles leave out (-1 and row_hi .. my+1)
+hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, hipStream_t st);
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,
                             const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
                             const double *Dxy, double *out, hipStream_t st);

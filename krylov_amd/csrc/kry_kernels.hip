@@ -607,7 +607,8 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int z0 = a.zlo + ch * a.zc;
 	const int z1 = min(z0 + a.zc, a.zhi + 1);   // exclusive
-	const int y0 = ty * TY - (GEN ? 1 : 0);     // first row (grid index j) of the tile
+	// (GEN: tile rows from j = -1, or from j = 0 with the rows outside the tiles left to g_bc_xy_rows: a.y_off)
+	const int y0 = ty * TY - (GEN ? a.y_off : 0);     // first row (grid index j) of the tile
 	const int c0 = 2 + tx * TXW;                // first column of the tile
 	const int col = c0 + 2 * lane;              // column of .x ; grid index i = col - 2
 	const int ix = col - 2;
@@ -1703,10 +1704,9 @@ __global__ void g_bc(double *d, KryGeo g, int dir)
 // The x faces and then the y faces of one plane per block: both treatments stay inside the plane
 // (BoundaryHandler.C:416-517), and the y treatment reads columns 0 and mx as the x treatment left
 // them, so the block's threads meet at a barrier in between.
-__global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
+__device__ inline void bc_xy_plane(double *d, const KryGeo &g, int k, int nthreads)
 {
-	const int k = (int)blockIdx.x - 1;
-	for (int j = (int)threadIdx.x - 1; j <= g.my + 1; j += (int)blockDim.x) {
+	for (int j = (int)threadIdx.x - 1; j <= g.my + 1; j += nthreads) {
 		double *row = d + kry_idx(g, 0, j, k);   // row[i] = value at grid index i
 		if (!g.nb[0]) {
 			if (g.bc[0] == 0) { row[-1] = 0.; row[0] = 0.; }
@@ -1723,7 +1723,7 @@ __global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
 	}
 	__threadfence_block();
 	__syncthreads();
-	for (int i = (int)threadIdx.x; i <= g.mx; i += (int)blockDim.x) {
+	for (int i = (int)threadIdx.x; i <= g.mx; i += nthreads) {
 		double *c = d + kry_idx(g, i, 0, k);     // c[j*px]
 		const long s = g.px;
 		if (!g.nb[2]) {
@@ -1739,6 +1739,52 @@ __global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
 			}
 		}
 	}
+}
+
+__global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
+{
+	bc_xy_plane(d, g, (int)blockIdx.x - 1, (int)blockDim.x);
+}
+
+// g_bc_xy for the output of a general-boundary stencil kernel whose tile rows start at j = 0 (a.y_off == 0):
+// the rows its tiles leave out -- j = -1 and j = row_hi .. my+1 -- first receive the vector update the
+// stencil kernel applies everywhere else (psi = X + c*Y into Xout, through do_BCs with INBC; the
+// reference's whole-array updates, solveLin_BICGStab.C:356-362, 392-394, act on every stored cell),
+// evaluated cell by cell from memory with the same roundings; then the x and y faces of the output.
+// The operator itself is not needed on those rows: j = -1 and my+1 are ghost rows, and its values on row my
+// (the only grid row that can be left out) are overwritten by the treatment of the upper y face before
+// anything reads them when both x faces are Dirichlet faces of the domain -- the case this variant is
+// launched for (an extrapolating x face would form the edge ghosts (-1, my), (mx+1, my) from them first).
+template <bool INBC>
+__global__ __launch_bounds__(1024) void g_bc_xy_rows(const KryFused a, int row_hi, int is_a, int defer)
+{
+	const KryGeo &g = a.g;
+	const int k = (int)blockIdx.x - 1;
+	const KryState *S = a.S;
+	if (!S->done) {
+		PsiSrc src;
+		src.X = a.X; src.Y = a.Y; src.Z1 = a.Z1; src.Z2 = a.Z2;
+		src.c = is_a ? -S->beta : -S->alpha;
+		src.nz = defer ? a.nz : 0;
+		src.dz1 = defer ? -S->gamma[S->L] : 0.;
+		src.dz2 = defer ? -S->gamma[1] : 0.;
+		const int nhi = max(0, g.my + 2 - row_hi), nrows = 1 + nhi, w = g.mx + 3;
+		// l = 1: the rows and planes of the output array that the operator does not write keep the old u1 (see k_fused)
+		const bool gplane = (k == -1 && !g.has_lo) || (k == g.mz + 1 && !g.has_hi);
+		const int hand_last = min(KRY_TXW * a.ntx - 1, g.mx + 1);
+		for (int t = (int)threadIdx.x; t < nrows * w; t += (int)blockDim.x) {
+			const int r = t / w, i = t - r * w - 1;
+			const int j = r == 0 ? -1 : row_hi + r - 1;
+			const long p = kry_idx(g, i, j, k);
+			double v = psi_raw(src, g, i, j, k);
+			if (INBC) v = bc_psi(src, g, v, i, j, k);
+			a.Xout[p] = v;
+			if (defer && src.nz >= 1 && i >= 0 && i <= hand_last && (gplane || j == -1 || j == g.my + 1)) a.O[p] = a.Z1[p];
+		}
+		__threadfence_block();
+		__syncthreads();
+	}
+	bc_xy_plane(a.O, g, k, (int)blockDim.x);
 }
 
 // Krylov::multiply_withMat on every point 0..m of the slab, neighbours read
@@ -2053,6 +2099,16 @@ hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs)
 	const int nt = std::min(1024, std::max(NT, ((std::max(g.mx + 1, g.my + 3) + 63) / 64) * 64));
 	hipLaunchKernelGGL(g_bc_xy, dim3(g.mz + 3), dim3(nt), 0, st, d, g);
 	if (ndirs > 2) hipLaunchKernelGGL(g_bc, dim3(cdiv(g.mx + 1, 64), g.my + 1), dim3(64), 0, st, d, g, 2);
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, hipStream_t st)
+{
+	const KryGeo &g = a.g;
+	const int nt = std::min(1024, std::max(NT, ((std::max(g.mx + 1, g.my + 3) + 63) / 64) * 64));
+	const int is_a = (kind == KF_A0 || kind == KF_A1) ? 1 : 0, defer = (kind == KF_A0) ? 1 : 0;
+	if (inbc) hipLaunchKernelGGL(g_bc_xy_rows<true>, dim3(g.mz + 3), dim3(nt), 0, st, a, row_hi, is_a, defer);
+	else hipLaunchKernelGGL(g_bc_xy_rows<false>, dim3(g.mz + 3), dim3(nt), 0, st, a, row_hi, is_a, defer);
 	return hipGetLastError();
 }
 

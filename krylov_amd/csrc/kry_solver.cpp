@@ -110,6 +110,9 @@ struct kry_solver {
 	bool fused = false;        // fused path in use (device-resident recurrences)
 	bool gen = false;          // its general-boundary variant (any face types)
 	bool inbc = false;         // ... with the operator's input passed through do_BCs (constant coefficients, Krylov.C:516)
+	bool gen_y0 = false;       // ... with tile rows 0 .. instead of -1 .. (the rows -1, my, my+1 are left to the face kernel:
+	                           // 64 instead of 65 tile rows at my = 512, which fills the block slots exactly); possible
+	                           // where the operator is not needed on row my: both x faces Dirichlet faces of the domain
 	// Cartesian split of the global domain over processes (mpi_manager.C:56-305): np
 	// sub-domains per direction, this process at co.  {1,1,nslabs} for plain z slabs.
 	int np[3] = {1, 1, 1}, co[3] = {0, 0, 0};
@@ -613,7 +616,8 @@ Tiling tiling(const kry_solver *h, const Slab &s)
 	Tiling t;
 	if (h->gen) {
 		t.ntx = (s.g.mx + KRY_TXW - 1) / KRY_TXW;       // columns i = 0 .. mx-1; -1, mx, mx+1 by the halo lanes
-		t.nty = (s.g.my + 3 + 8 - 1) / 8;                // rows    j = -1 .. my+1
+		t.nty = h->gen_y0 ? (s.g.my + 8 - 1) / 8         // rows    j = 0 .. my-1 (the others: kry_launch_bcs_rows)
+		                  : (s.g.my + 3 + 8 - 1) / 8;    // rows    j = -1 .. my+1
 		t.zlo = 0;
 		t.zhi = s.g.mz;
 	} else {
@@ -643,6 +647,7 @@ KryFused fused_base(kry_solver *h, Slab &s, int phase)
 	a.zlo = t.zlo; a.zhi = t.zhi; a.zc = h->zc;
 	a.ntx = t.ntx; a.nty = t.nty; a.nchunk = t.nchunk; a.nblk = t.nblk;
 	a.ch_sel = 0;
+	a.y_off = h->gen_y0 ? 0 : 1;
 	a.blk_off = 0;
 	a.red = make_red(s, t.nblk, phase);
 	return a;
@@ -738,7 +743,9 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 				CHK(halo_wait(h));
 				CHK(launch_fused(h, s, kind, a, 1));
 			}
-			HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));   // the z faces follow in k_surf
+			// the x and y faces of the output (the z faces follow in k_surf)
+			if (h->gen_y0) HIPCHK(kry_launch_bcs_rows(kind, a, 8 * a.nty, h->inbc, s.st));
+			else HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));
 		}
 		// planes 1 and mz-1, the ones the z neighbours need, are final once the x and y faces
 		// are treated: their exchange runs beside k_surf (z faces, boundary-plane dot terms)
@@ -1529,7 +1536,7 @@ void choose_chunk_depth(kry_solver *h)
 	if (h->zc_fixed) return;
 	const KryGeo &g = h->slabs[0].g;
 	const int ty = h->gen ? 8 : h->ty;
-	const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + (h->gen ? 3 : 0) + ty - 1) / ty);
+	const int tiles = ((g.mx + KRY_TXW - 1) / KRY_TXW) * ((g.my + ((h->gen && !h->gen_y0) ? 3 : 0) + ty - 1) / ty);
 	const int chunks = std::max(1, (1024 + tiles - 1) / tiles);
 	// planes a stencil kernel evaluates: the faces of the domain are skipped on Dirichlet faces,
 	// interface planes and general faces are not (taken equal on all slabs of a split)
@@ -1588,6 +1595,9 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	for (int f = 0; f < 6; ++f) extrapolating = extrapolating && (h->d.bc_type[f] == 0 || h->d.bc_type[f] == 1);
 	h->gen = can_fuse && extrapolating && (!dirichlet || h->cart);
 	h->inbc = h->gen && !var && !dirichlet;
+	// (KRY_GEN_Y0=0: tile rows from -1 everywhere, for comparisons)
+	h->gen_y0 = h->gen && !h->cart && h->d.bc_type[0] == 0 && h->d.bc_type[1] == 0 &&
+	            !(getenv("KRY_GEN_Y0") && atoi(getenv("KRY_GEN_Y0")) == 0);
 	h->fused = can_fuse && ((dirichlet && !h->cart) || h->gen);
 	choose_chunk_depth(h);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
@@ -2394,7 +2404,7 @@ int kry_get_stats(kry_handle h, kry_stats *o)
 	o->staged_fields = h->staged_fields;
 	o->overlapped_exchanges = h->overlapped_exchanges;
 	o->slab_link = h->slab_link ? 1 : 0;
-	o->tile_rows = h->gen ? 8 : h->ty;
+	o->tile_rows = h->gen ? (h->gen_y0 ? -8 : 8) : h->ty;     // (negative: general-boundary tiles that start at row 0)
 	o->chunk_planes = h->zc;
 	o->stream_blocks = h->stream_blocks;
 	return 0;

@@ -32,6 +32,7 @@ static int g_mode = 0;          /* 0 off, 1 fused Dirichlet path, 2 generic path
 static int g_ty = 8, g_zc = 16, g_sb = 2048;
 static int g_nslabs = 1;        /* z slabs of the device run (sums are formed per slab, then added in slab order) */
 static int g_split = 0;         /* 1: the stencil kernels of a multi-slab run are launched in two parts (edge chunks first) */
+static int g_gen_y0 = 0;        /* 1: the general-boundary tiles start at grid row 0 (rows 0 .. my-1 tiled) instead of -1 */
 
 /* one z slab of the global box: local plane k is global plane z0 + k */
 typedef struct { int z0, mz, has_lo, has_hi; } zslab;
@@ -239,7 +240,7 @@ static double fused_gen_sum_slab(const orc_cfg *c, const double *A, const double
 {
 	const hbox b = hb(c);
 	const int ty = 8, zc = g_zc, VD = ty / NW;
-	const int ntx = (b.mx + 127) / 128, nty = (b.my + 3 + ty - 1) / ty;
+	const int ntx = (b.mx + 127) / 128, nty = g_gen_y0 ? (b.my + ty - 1) / ty : (b.my + 3 + ty - 1) / ty;
 	const int zlo = 0, zhi = sl.mz;
 	const int nchunk = (zhi - zlo + 1 + zc - 1) / zc;
 	const long nf = (long)ntx * nty * nchunk;
@@ -256,7 +257,7 @@ static double fused_gen_sum_slab(const orc_cfg *c, const double *A, const double
 		const int tx = (int)(bid % ntx), tyi = (int)((bid / ntx) % nty), ch = (int)(bid / ((long)ntx * nty));
 		const int z0 = zlo + ch * zc;
 		const int z1 = (z0 + zc < zhi + 1) ? z0 + zc : zhi + 1;
-		const int y0 = tyi * ty - 1;
+		const int y0 = tyi * ty - (g_gen_y0 ? 0 : 1);
 		double acc[NT];
 		for (int t = 0; t < NT; ++t) {
 			const int w = t >> 6, lane = t & 63;
@@ -462,6 +463,7 @@ void orc_use_gpu_order(int enable, int ty, int zc, int stream_blocks)
 {
 	g_mode = enable;
 	if (ty > 0) g_ty = ty;
+	g_gen_y0 = ty < 0;              /* kry_stats.tile_rows < 0 (general-boundary path: always 8 rows) */
 	if (zc > 0) g_zc = zc;
 	if (stream_blocks > 0) g_sb = stream_blocks;
 	orc_set_reduce_hook(enable ? hook : NULL, NULL);
