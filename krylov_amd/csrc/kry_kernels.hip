@@ -799,11 +799,12 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	store_psi(pc, z0);
 	issue(z0 + 1);
 	// one-pass operands of the stencil (lambda, r~) are fetched one plane ahead as well: nothing the
-	// stencil of a plane waits for is requested in the same step (256^3 constant coefficients: -2.5 %)
-	// (not where the registers for it would cost a resident block or spill: the instantiations with
-	// Dxy and the general-boundary ones with field coefficients fetch them in the step itself)
+	// stencil of a plane waits for is requested in the same step (256^3 constant coefficients: -2.5 %;
+	// general faces with field coefficients, 512^3: -6 %, still two blocks per compute unit at 245-251
+	// registers).  Not in the instantiations with Dxy: measured without effect there, and the first
+	// kernel of a pass would lose a resident block to it.
 	constexpr bool HAS_RT = (KIND == KF_A0 || KIND == KF_A1 || KIND == KF_B0);
-	constexpr bool PFC = !OFFD && !(GEN && VAR);
+	constexpr bool PFC = !OFFD;
 	double2 lamn[VD], rtn[HAS_RT ? VD : 1];
 	auto issue_coef = [&](int z) {
 		const long pbn = plane(z);
