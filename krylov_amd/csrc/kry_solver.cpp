@@ -1740,9 +1740,11 @@ int link_probe(kry_solver *h)
 // Decides whether the slabs of this process exchange through the link, sets it up and tries it.
 // Kernels of different slabs then wait for each other, so they must be able to run side by side:
 // by default the link is made when every slab has a device of its own and all those devices can
-// address each other; KRY_SLAB_LINK=1 also allows two slabs on one device (their four streams get
-// the device's four hardware queues), KRY_SLAB_LINK=0 keeps copies and events.  Never fatal: when
-// anything fails the slabs exchange by copies as before and kry_stats.slab_link stays 0.
+// address each other; KRY_SLAB_LINK=1 also allows two slabs on one device (their four streams must
+// then sit on four different hardware queues of the device -- a process hands its queues out in turn,
+// so that holds in a fresh process; where two of them share a queue the trial below times out),
+// KRY_SLAB_LINK=0 keeps copies and events.  Never fatal: when anything fails the slabs exchange by
+// copies as before and kry_stats.slab_link stays 0.
 int link_local_slabs(kry_solver *h)
 {
 	const int ns = (int)h->slabs.size();
