@@ -120,7 +120,9 @@ hipError_t kry_launch_sub(double *dst, const double *x, const double *y, long n,
 hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs = 3);   // x, y[, z] faces
 // x and y faces of the output a.O of a general-boundary stencil kernel launched with y_off == 0, after the
 // vector update of the rows its tiles leave out (-1 and row_hi .. my+1)
-hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, hipStream_t st);
+// (where an x face of the domain extrapolates, also the operator on the four points of row my that its treatment reads)
+hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, bool var, bool offd, bool exact,
+                               hipStream_t st);
 hipError_t kry_launch_gspmv(const KryGeo &g, const KryOp &op, bool var, bool offd, const double *psi,
                             const double *lam, const double *Dxx, const double *Dyy, const double *Dzz,
                             const double *Dxy, double *out, hipStream_t st);

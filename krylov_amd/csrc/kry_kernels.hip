@@ -1752,12 +1752,15 @@ __global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
 // stencil kernel applies everywhere else (psi = X + c*Y into Xout, through do_BCs with INBC; the
 // reference's whole-array updates, solveLin_BICGStab.C:356-362, 392-394, act on every stored cell),
 // evaluated cell by cell from memory with the same roundings; then the x and y faces of the output.
-// The operator itself is not needed on those rows: j = -1 and my+1 are ghost rows, and its values on row my
-// (the only grid row that can be left out) are overwritten by the treatment of the upper y face before
-// anything reads them when both x faces are Dirichlet faces of the domain -- the case this variant is
-// launched for (an extrapolating x face would form the edge ghosts (-1, my), (mx+1, my) from them first).
-template <bool INBC>
-__global__ __launch_bounds__(1024) void g_bc_xy_rows(const KryFused a, int row_hi, int is_a, int defer)
+// The operator itself is hardly needed on those rows: j = -1 and my+1 are ghost rows, and its values on
+// row my (the only grid row that can be left out) are overwritten by the treatment of the upper y face
+// before anything reads them -- except that an extrapolating x face, treated first and over all rows
+// (BoundaryHandler.C:420-460), forms the edge ghosts (-1, my), (mx, my), (mx+1, my) from the values at
+// i = 0, 1 resp. mx-2, mx-1 of that row: with `op_row` those four values per plane are evaluated here,
+// psi at their neighbours formed from memory like everything else in this kernel (same roundings as
+// in k_fused, same apply_op).
+template <bool INBC, bool VAR, bool OFFD, bool EXACT>
+__global__ __launch_bounds__(1024) void g_bc_xy_rows(const KryFused a, int row_hi, int is_a, int defer, int op_row)
 {
 	const KryGeo &g = a.g;
 	const int k = (int)blockIdx.x - 1;
@@ -1781,6 +1784,32 @@ __global__ __launch_bounds__(1024) void g_bc_xy_rows(const KryFused a, int row_h
 			if (INBC) v = bc_psi(src, g, v, i, j, k);
 			a.Xout[p] = v;
 			if (defer && src.nz >= 1 && i >= 0 && i <= hand_last && (gplane || j == -1 || j == g.my + 1)) a.O[p] = a.Z1[p];
+		}
+		if (op_row && k >= 0 && k <= g.mz && threadIdx.x < 4) {
+			const int i = threadIdx.x < 2 ? (int)threadIdx.x : g.mx - 4 + (int)threadIdx.x, j = g.my;
+			auto P = [&](int ii, int jj, int kk) -> double {
+				const double v = psi_raw(src, g, ii, jj, kk);
+				return INBC ? bc_psi(src, g, v, ii, jj, kk) : v;
+			};
+			const long p = kry_idx(g, i, j, k), sx = g.px, sz = g.ps;
+			Sten s;
+			s.pc = P(i, j, k); s.xm = P(i - 1, j, k); s.xp = P(i + 1, j, k);
+			s.ym = P(i, j - 1, k); s.yp = P(i, j + 1, k); s.zm = P(i, j, k - 1); s.zp = P(i, j, k + 1);
+			s.lam = a.lam[p];
+			if (VAR) {
+				s.dxx = a.Dxx[p]; s.dyy = a.Dyy[p]; s.dzz = a.Dzz[p];
+				s.dxx_m = a.Dxx[p - 1]; s.dxx_p = a.Dxx[p + 1];
+				s.dyy_m = a.Dyy[p - sx]; s.dyy_p = a.Dyy[p + sx];
+				s.dzz_m = a.Dzz[p - sz]; s.dzz_p = a.Dzz[p + sz];
+				if (OFFD) {
+					s.dxy = a.Dxy[p];
+					s.dxy_xm = a.Dxy[p - 1]; s.dxy_xp = a.Dxy[p + 1];
+					s.dxy_ym = a.Dxy[p - sx]; s.dxy_yp = a.Dxy[p + sx];
+					s.pmm = P(i - 1, j - 1, k); s.pmp = P(i - 1, j + 1, k);
+					s.ppm = P(i + 1, j - 1, k); s.ppp = P(i + 1, j + 1, k);
+				}
+			}
+			a.O[p] = apply_op<VAR, OFFD, EXACT>(s, a.op);
 		}
 		__threadfence_block();
 		__syncthreads();
@@ -2103,13 +2132,21 @@ hipError_t kry_launch_bcs(double *d, const KryGeo &g, hipStream_t st, int ndirs)
 	return hipGetLastError();
 }
 
-hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, hipStream_t st)
+hipError_t kry_launch_bcs_rows(int kind, const KryFused &a, int row_hi, bool inbc, bool var, bool offd, bool exact,
+                               hipStream_t st)
 {
 	const KryGeo &g = a.g;
 	const int nt = std::min(1024, std::max(NT, ((std::max(g.mx + 1, g.my + 3) + 63) / 64) * 64));
 	const int is_a = (kind == KF_A0 || kind == KF_A1) ? 1 : 0, defer = (kind == KF_A0) ? 1 : 0;
-	if (inbc) hipLaunchKernelGGL(g_bc_xy_rows<true>, dim3(g.mz + 3), dim3(nt), 0, st, a, row_hi, is_a, defer);
-	else hipLaunchKernelGGL(g_bc_xy_rows<false>, dim3(g.mz + 3), dim3(nt), 0, st, a, row_hi, is_a, defer);
+	// row my is left out by the tiles and an x face of the domain extrapolates
+	const int op_row = (row_hi <= g.my && ((!g.nb[0] && g.bc[0] == 1) || (!g.nb[1] && g.bc[1] == 1))) ? 1 : 0;
+	dim3 grid(g.mz + 3), block(nt);
+#define KRY_ROWS(I, V, O, E) hipLaunchKernelGGL((g_bc_xy_rows<I, V, O, E>), grid, block, 0, st, a, row_hi, is_a, defer, op_row)
+	if (!var && inbc) KRY_ROWS(true, false, false, true);
+	else if (!var) KRY_ROWS(false, false, false, true);
+	else if (!offd) { if (exact) KRY_ROWS(false, true, false, true); else KRY_ROWS(false, true, false, false); }
+	else { if (exact) KRY_ROWS(false, true, true, true); else KRY_ROWS(false, true, true, false); }
+#undef KRY_ROWS
 	return hipGetLastError();
 }
 

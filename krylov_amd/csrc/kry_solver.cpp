@@ -111,8 +111,8 @@ struct kry_solver {
 	bool gen = false;          // its general-boundary variant (any face types)
 	bool inbc = false;         // ... with the operator's input passed through do_BCs (constant coefficients, Krylov.C:516)
 	bool gen_y0 = false;       // ... with tile rows 0 .. instead of -1 .. (the rows -1, my, my+1 are left to the face kernel:
-	                           // 64 instead of 65 tile rows at my = 512, which fills the block slots exactly); possible
-	                           // where the operator is not needed on row my: both x faces Dirichlet faces of the domain
+	                           // 64 instead of 65 tile rows at my = 512, which fills the block slots exactly); not for a
+	                           // Cartesian split (a y neighbour above needs the operator on the whole row my)
 	// Cartesian split of the global domain over processes (mpi_manager.C:56-305): np
 	// sub-domains per direction, this process at co.  {1,1,nslabs} for plain z slabs.
 	int np[3] = {1, 1, 1}, co[3] = {0, 0, 0};
@@ -744,7 +744,7 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 				CHK(launch_fused(h, s, kind, a, 1));
 			}
 			// the x and y faces of the output (the z faces follow in k_surf)
-			if (h->gen_y0) HIPCHK(kry_launch_bcs_rows(kind, a, 8 * a.nty, h->inbc, s.st));
+			if (h->gen_y0) HIPCHK(kry_launch_bcs_rows(kind, a, 8 * a.nty, h->inbc, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 			else HIPCHK(kry_launch_bcs(a.O, s.g, s.st, 2));
 		}
 		// planes 1 and mz-1, the ones the z neighbours need, are final once the x and y faces
@@ -1596,8 +1596,7 @@ int load_common(kry_solver *h, bool var, bool offd, const double Dc[3], const do
 	h->gen = can_fuse && extrapolating && (!dirichlet || h->cart);
 	h->inbc = h->gen && !var && !dirichlet;
 	// (KRY_GEN_Y0=0: tile rows from -1 everywhere, for comparisons)
-	h->gen_y0 = h->gen && !h->cart && h->d.bc_type[0] == 0 && h->d.bc_type[1] == 0 &&
-	            !(getenv("KRY_GEN_Y0") && atoi(getenv("KRY_GEN_Y0")) == 0);
+	h->gen_y0 = h->gen && !h->cart && !(getenv("KRY_GEN_Y0") && atoi(getenv("KRY_GEN_Y0")) == 0);
 	h->fused = can_fuse && ((dirichlet && !h->cart) || h->gen);
 	choose_chunk_depth(h);
 	CHK(stage_common(h, phi, rhs, lam, Dxx, Dyy, Dzz, Dxy));
