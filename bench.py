@@ -789,8 +789,8 @@ def main():
         if world == 1 and not args.weak and not args.no_also:
             # the same driver run also times l = 1 on this grid and the 256^3 constant-coefficient problem
             also = []
-            for (an, aL, awl, asteps, awarm) in ((n, 1 if L == 2 else 2, args.workload, 20, 3), (256, 1, "const", 200, 20),
-                                                 (256, 2, "const", 100, 10)):
+            for (an, aL, awl, asteps, awarm) in ((n, 1 if L == 2 else 2, args.workload, 20, 3), (256, 1, "const", 400, 100),
+                                                 (256, 2, "const", 200, 50)):
                 try:
                     also.append(single_gpu_passes(capi, device, an, aL, awl, asteps, awarm,
                                                   fields=f if (an == n and awl == args.workload) else None))
