@@ -86,6 +86,9 @@ hipError_t kry_launch_fused(int kind, int ty, const KryFused &a, bool var, bool 
                             hipStream_t st);
 // inbc: constant coefficients with a face that is not Dirichlet -- the operator's input passes through do_BCs
 hipError_t kry_launch_fused_gen(int kind, const KryFused &a, bool var, bool offd, bool exact, bool inbc, hipStream_t st);
+// ... and then this goes first: the treated input on and behind the faces, into a.Xout (the operands' ghost cells
+// must be current; the kernel launched with inbc reads them back)
+hipError_t kry_launch_psi_shell(int kind, const KryFused &a, hipStream_t st);
 int kry_fused_blocks_per_cu(int ty, bool var, bool offd, bool exact, bool gen);
 hipError_t kry_launch_surf(int kind, const KryFused &a, int nblk, hipStream_t st);
 hipError_t kry_launch_mgs2(const KryStream &a, int nbx, int nby, hipStream_t st);

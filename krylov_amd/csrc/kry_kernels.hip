@@ -525,7 +525,9 @@ template <> struct KindTraits<KF_SPMV> { static constexpr int ND = 1; static con
 // (Compiled for the register budget the code wants -- 2 blocks per CU for the field-coefficient
 // tiles.  Forcing 3 or 4 blocks per CU through __launch_bounds__ ran 3-25 % slower at 512^3.)
 // INBC (constant coefficients on faces that are not all Dirichlet): psi is passed through
-// do_BCs before the operator reads it and before it is stored, as Krylov.C:516 does.
+// do_BCs before the operator reads it and before it is stored, as Krylov.C:516 does.  That
+// changes cells on and behind the faces only; g_psi_shell evaluates them ahead of this
+// kernel, which reads them back where a tile or its halo ring holds such a cell.
 template <int KIND, int TY, bool VAR, bool OFFD, bool EXACT, bool GEN, bool INBC = false>
 __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 {
@@ -669,15 +671,23 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 
 	auto plane = [&](int z) -> long { return (long)(z + 1) * g.ps; };
 
-	// input treatment of the constant-coefficient operator: where the untreated operands live
-	PsiSrc bsrc;
-	bsrc.X = a.X; bsrc.Y = a.Y; bsrc.Z1 = a.Z1; bsrc.Z2 = a.Z2;
-	bsrc.c = cpsi; bsrc.dz1 = dz1; bsrc.dz2 = dz2; bsrc.nz = nz;
+	// input treatment of the constant-coefficient operator (INBC): the treated psi of every cell that is not
+	// strictly inside the box was written to Xout by g_psi_shell before this launch; those cells take it from
+	// there (fetched with the operands of their plane) instead of forming psi from the operands.
+	const bool fx = INBC && (ix <= 0 || ix >= g.mx), fy = INBC && (ix + 1 <= 0 || ix + 1 >= g.mx);
+	bool frow[VD];
+#pragma unroll
+	for (int e = 0; e < VD; ++e) frow[e] = INBC && (y0 + w * VD + e <= 0 || y0 + w * VD + e >= g.my);
+	const bool fh = INBC && (y0 + (hr ? TY : -1) <= 0 || y0 + (hr ? TY : -1) >= g.my);
+	const bool fc = INBC && (ccol - 2 <= 0 || ccol - 2 >= g.mx || y0 + crr - 1 <= 0 || y0 + crr - 1 >= g.my);
+	double2 bx[INBC ? VD : 1], hb = {0., 0.};
+	double sb = 0.;
 	int zi = 0;          // the plane whose operands were issued last
-	auto bc2 = [&](double2 v, int i, int j) __attribute__((always_inline)) -> double2 {
+	auto bc2 = [&](double2 v, double2 t, bool frw) __attribute__((always_inline)) -> double2 {
 		if (INBC) {
-			v.x = bc_psi(bsrc, g, v.x, i, j, zi);
-			v.y = bc_psi(bsrc, g, v.y, i + 1, j, zi);
+			const bool fz = (zi <= 0 || zi >= g.mz);
+			if (fz || frw || fx) v.x = t.x;
+			if (fz || frw || fy) v.y = t.y;
 		}
 		return v;
 	};
@@ -717,6 +727,14 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 			if (DEFER && nz >= 1) sz1 = a.Z1[pb + coff];
 			if (DEFER && nz >= 2) sz2 = a.Z2[pb + coff];
 		}
+		if (INBC) {
+			const bool fz = (z <= 0 || z >= g.mz);
+#pragma unroll
+			for (int e = 0; e < VD; ++e)
+				if (fz || frow[e] || fx || fy) bx[INBC ? e : 0] = ld2(a.Xout + pb + off[e]);
+			if (hrow && (fz || fh || fx || fy)) hb = ld2(a.Xout + pb + hoff);
+			if (cload && (fz || fc)) sb = a.Xout[pb + coff];
+		}
 	};
 	// psi = X + c*Y, with Y first brought up to date where its last update was deferred
 	auto psi2 = [&](double2 x, double2 y, double2 z1, double2 z2) -> double2 {
@@ -735,18 +753,18 @@ __global__ __launch_bounds__(NT) void k_fused(const KryFused a)
 	auto own_psi = [&](double2 (&dst)[VD]) {
 #pragma unroll
 		for (int e = 0; e < VD; ++e)
-			dst[e] = bc2(psi2(nx[e], ny[e], nz1[DEFER ? e : 0], nz2[DEFER ? e : 0]), ix, y0 + w * VD + e);
+			dst[e] = bc2(psi2(nx[e], ny[e], nz1[DEFER ? e : 0], nz2[DEFER ? e : 0]), bx[INBC ? e : 0], frow[e]);
 	};
 	// psi of the issued plane at this lane's halo-column cell
 	auto col_psi = [&]() __attribute__((always_inline)) -> double {
 		const double v = psi1(sx, sy, sz1, sz2);
-		return INBC ? bc_psi(bsrc, g, v, ccol - 2, y0 + crr - 1, zi) : v;
+		return (INBC && (fc || zi <= 0 || zi >= g.mz)) ? sb : v;
 	};
 	// write psi (own + halo) of the issued plane into an LDS buffer
 	auto to_lds = [&](const double2 (&v)[VD], double *buf) {
 #pragma unroll
 		for (int e = 0; e < VD; ++e) st2(buf + lidx[e], v[e]);
-		if (hrow) st2(buf + hl, bc2(psi2(hx, hy, hz1, hz2), ix, y0 + (hr ? TY : -1)));
+		if (hrow) st2(buf + hl, bc2(psi2(hx, hy, hz1, hz2), hb, fh));
 		if (hcol && (!GEN || cside < 2)) buf[cl] = col_psi();
 	};
 	// store psi to its ping-pong partner at interior points of plane z
@@ -1747,6 +1765,49 @@ __global__ __launch_bounds__(1024) void g_bc_xy(double *d, KryGeo g)
 	bc_xy_plane(d, g, (int)blockIdx.x - 1, (int)blockDim.x);
 }
 
+// Input treatment of the constant-coefficient operator on general faces, ahead of a fused stencil
+// kernel: psi = X + c*Y (the kernel's vector update) after do_BCs (Krylov.C:516) for every stored cell
+// that is not strictly inside the box -- planes k <= 0 and k >= mz whole, rows j <= 0 and j >= my of the
+// planes between, cells i <= 0 and i >= mx of the rows between -- one cell per thread through bc_psi,
+// into Xout.  Strictly inside the box do_BCs changes nothing, and k_fused forms psi there itself.
+__global__ __launch_bounds__(256) void g_psi_shell(const KryFused a, int is_a, int defer)
+{
+	const KryGeo &g = a.g;
+	const KryState *S = a.S;
+	if (S->done) return;
+	PsiSrc src;
+	src.X = a.X; src.Y = a.Y; src.Z1 = a.Z1; src.Z2 = a.Z2;
+	src.c = is_a ? -S->beta : -S->alpha;
+	src.nz = defer ? a.nz : 0;
+	src.dz1 = defer ? -S->gamma[S->L] : 0.;
+	src.dz2 = defer ? -S->gamma[1] : 0.;
+	const long w = g.mx + 3, np = w * (g.my + 3), nrow = 4 * w, nc = nrow + 4L * (g.my - 1);
+	long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= 4 * np + (long)(g.mz - 1) * nc) return;
+	int i, j, k;
+	if (t < 4 * np) {
+		const int q = (int)(t / np), r = (int)(t - q * np);
+		k = q < 2 ? q - 1 : g.mz + q - 2;
+		j = r / (int)w - 1;
+		i = r % (int)w - 1;
+	} else {
+		t -= 4 * np;
+		k = 1 + (int)(t / nc);
+		int r = (int)(t % nc);
+		if (r < nrow) {
+			const int q = r / (int)w;
+			j = q < 2 ? q - 1 : g.my + q - 2;
+			i = r % (int)w - 1;
+		} else {
+			r -= (int)nrow;
+			const int q = r & 3;
+			j = 1 + (r >> 2);
+			i = q < 2 ? q - 1 : g.mx + q - 2;
+		}
+	}
+	a.Xout[kry_idx(g, i, j, k)] = bc_psi(src, g, psi_raw(src, g, i, j, k), i, j, k);
+}
+
 // g_bc_xy for the output of a general-boundary stencil kernel whose tile rows start at j = 0 (a.y_off == 0):
 // the rows its tiles leave out -- j = -1 and j = row_hi .. my+1 -- first receive the vector update the
 // stencil kernel applies everywhere else (psi = X + c*Y into Xout, through do_BCs with INBC; the
@@ -1780,9 +1841,7 @@ __global__ __launch_bounds__(1024) void g_bc_xy_rows(const KryFused a, int row_h
 			const int r = t / w, i = t - r * w - 1;
 			const int j = r == 0 ? -1 : row_hi + r - 1;
 			const long p = kry_idx(g, i, j, k);
-			double v = psi_raw(src, g, i, j, k);
-			if (INBC) v = bc_psi(src, g, v, i, j, k);
-			a.Xout[p] = v;
+			if (!INBC) a.Xout[p] = psi_raw(src, g, i, j, k);       // (INBC: g_psi_shell has written these rows)
 			if (defer && src.nz >= 1 && i >= 0 && i <= hand_last && (gplane || j == -1 || j == g.my + 1)) a.O[p] = a.Z1[p];
 		}
 		if (op_row && k >= 0 && k <= g.mz && threadIdx.x < 4) {
@@ -1944,6 +2003,16 @@ static hipError_t launch_fused_gen_t(const KryFused &a, bool var, bool offd, boo
 	else if (!offd) { if (exact) KRY_LAUNCH(true, false, true); else KRY_LAUNCH(true, false, false); }
 	else { if (exact) KRY_LAUNCH(true, true, true); else KRY_LAUNCH(true, true, false); }
 #undef KRY_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t kry_launch_psi_shell(int kind, const KryFused &a, hipStream_t st)
+{
+	const KryGeo &g = a.g;
+	if (g.mx < 1 || g.my < 1 || g.mz < 1) return hipErrorInvalidValue;
+	const long w = g.mx + 3, total = 4 * w * (g.my + 3) + (long)(g.mz - 1) * (4 * w + 4L * (g.my - 1));
+	const int is_a = (kind == KF_A0 || kind == KF_A1) ? 1 : 0, defer = (kind == KF_A0) ? 1 : 0;
+	hipLaunchKernelGGL(g_psi_shell, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, is_a, defer);
 	return hipGetLastError();
 }
 

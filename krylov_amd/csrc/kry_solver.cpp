@@ -658,6 +658,7 @@ int launch_fused(kry_solver *h, Slab &s, int kind, const KryFused &a, int prof =
 {
 	HIPCHK(hipSetDevice(s.device));
 	if (prof & 1) prof_begin(h, s, kind);
+	if (h->gen && h->inbc) HIPCHK(kry_launch_psi_shell(kind, a, s.st));
 	if (h->gen) HIPCHK(kry_launch_fused_gen(kind, a, h->var, h->offd, h->op.exact_rcp != 0, h->inbc, s.st));
 	else HIPCHK(kry_launch_fused(kind, h->ty, a, h->var, h->offd, h->op.exact_rcp != 0, s.st));
 	if (prof & 2) prof_end(h, s);
@@ -725,7 +726,9 @@ int stencil_step(kry_solver *h, int kind, MakeArgs &&make_args)
 			const int nsurf = surf_blocks(s.g);
 			a.red.nblk = a.nblk + nsurf;
 			int ib[6];
-			const int inner = h->halo_pending ? inner_tiles(s.g, a, ib) : 0;
+			// (with the operator's input treated ahead of the stencil kernel -- inbc -- that treatment reads ghost
+			// cells of the operands at the faces of the whole box: no tiles ahead of the exchange then)
+			const int inner = (h->halo_pending && !h->inbc) ? inner_tiles(s.g, a, ib) : 0;
 			if (inner > 0 && inner < a.nblk) {
 				// the ghost cells of an operand are still on their way: the tiles that read none of them
 				// first, the others when the exchange is done (one reduction over both launches)
