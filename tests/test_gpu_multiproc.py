@@ -24,6 +24,13 @@ def make_problem(kind):
     if kind == "const":
         p = P.reference_test1(32)
         p.rhs = P.interior_only(rng.uniform(-1, 1, p.rhs.shape))
+    elif kind == "const_faces":
+        # constant coefficients on faces that are not all Dirichlet: the operator's input passes through do_BCs
+        # (Krylov.C:516), here with ghost cells of neighbouring sub-domains among the cells that treatment reads
+        p = P.reference_test1(32)
+        p.bc = (1, 0, 1, 1, 0, 1)
+        p.rhs = rng.uniform(-1, 1, p.rhs.shape)
+        p.phi = 1e-2 * rng.uniform(-1, 1, p.phi.shape)
     elif kind == "var":
         p = P.smooth_var(32)
         p.rhs = rng.uniform(-1, 1, p.rhs.shape)
@@ -77,7 +84,8 @@ def run_ranks(world, kind, L, max_outer, eps, outdir, nproc=None):
 @gpu
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("kind,L", [("const", 1), ("var", 2), ("mixed", 2), ("mixed", 1), ("mixed_generic", 2),
-                                    ("var", 3), ("mixed", 4), ("offdiag_edge", 2)])
+                                    ("var", 3), ("mixed", 4), ("offdiag_edge", 2), ("const_faces", 1),
+                                    ("const_faces", 2)])
 def test_processes_reproduce_the_single_process_solve(tmp_path, kind, L, world):
     from helpers import points, rel_l2
     from krylov_amd import capi
@@ -106,7 +114,7 @@ ALL_SPLITS = [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 2, 2), (2, 2, 2)]
 # three kinds on every split, the others on the x-y split and the full split (one of them on the full split only)
 CART_CASES = [(k, L, n) for (k, L) in (("var", 2), ("mixed32", 2), ("offdiag", 2)) for n in ALL_SPLITS] + \
              [(k, L, n) for (k, L) in (("const", 2), ("var", 1), ("var_generic", 2), ("offdiag", 3), ("offdiag_edge", 2),
-                                       ("offdiag_edge", 1)) for n in ((2, 2, 1), (2, 2, 2))] + [("const_generic", 1, (2, 2, 2))]
+                                       ("offdiag_edge", 1), ("const_faces", 2), ("const_faces", 1)) for n in ((2, 2, 1), (2, 2, 2))] + [("const_generic", 1, (2, 2, 2))]
 
 
 @gpu
