@@ -1781,27 +1781,29 @@ __global__ __launch_bounds__(256) void g_psi_shell(const KryFused a, int is_a, i
 	src.nz = defer ? a.nz : 0;
 	src.dz1 = defer ? -S->gamma[S->L] : 0.;
 	src.dz2 = defer ? -S->gamma[1] : 0.;
-	const long w = g.mx + 3, np = w * (g.my + 3), nrow = 4 * w, nc = nrow + 4L * (g.my - 1);
-	long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= 4 * np + (long)(g.mz - 1) * nc) return;
+	// (cell counts fit 32 bits: checked by the launcher)
+	const unsigned w = g.mx + 3, np = w * (g.my + 3), nrow = 4 * w, nc = nrow + 4u * (g.my - 1);
+	unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= 4 * np + (unsigned)(g.mz - 1) * nc) return;
 	int i, j, k;
 	if (t < 4 * np) {
-		const int q = (int)(t / np), r = (int)(t - q * np);
-		k = q < 2 ? q - 1 : g.mz + q - 2;
-		j = r / (int)w - 1;
-		i = r % (int)w - 1;
+		const unsigned q = t / np, r = t - q * np, jr = r / w;
+		k = q < 2 ? (int)q - 1 : g.mz + (int)q - 2;
+		j = (int)jr - 1;
+		i = (int)(r - jr * w) - 1;
 	} else {
 		t -= 4 * np;
-		k = 1 + (int)(t / nc);
-		int r = (int)(t % nc);
+		const unsigned kk = t / nc;
+		unsigned r = t - kk * nc;
+		k = 1 + (int)kk;
 		if (r < nrow) {
-			const int q = r / (int)w;
-			j = q < 2 ? q - 1 : g.my + q - 2;
-			i = r % (int)w - 1;
+			const unsigned q = r / w;
+			j = q < 2 ? (int)q - 1 : g.my + (int)q - 2;
+			i = (int)(r - q * w) - 1;
 		} else {
-			r -= (int)nrow;
-			const int q = r & 3;
-			j = 1 + (r >> 2);
+			r -= nrow;
+			const int q = (int)(r & 3);
+			j = 1 + (int)(r >> 2);
 			i = q < 2 ? q - 1 : g.mx + q - 2;
 		}
 	}
@@ -2011,6 +2013,7 @@ hipError_t kry_launch_psi_shell(int kind, const KryFused &a, hipStream_t st)
 	const KryGeo &g = a.g;
 	if (g.mx < 1 || g.my < 1 || g.mz < 1) return hipErrorInvalidValue;
 	const long w = g.mx + 3, total = 4 * w * (g.my + 3) + (long)(g.mz - 1) * (4 * w + 4L * (g.my - 1));
+	if (total > 0x7fffffffL) return hipErrorInvalidValue;
 	const int is_a = (kind == KF_A0 || kind == KF_A1) ? 1 : 0, defer = (kind == KF_A0) ? 1 : 0;
 	hipLaunchKernelGGL(g_psi_shell, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, is_a, defer);
 	return hipGetLastError();

@@ -1,5 +1,5 @@
 # scratch driver for gpurun calls: put the commands of the next GPU run here
 set -e
-timeout -k 10 300 python bench.py --no-cpu > gpurun_out/s27_bench.json 2> gpurun_out/s27.err
-timeout -k 10 300 python bench.py --no-cpu > gpurun_out/s27_bench2.json 2>> gpurun_out/s27.err
-echo ok
+timeout -k 10 600 python -u -m pytest tests/test_gpu_bitwise.py -k "constant_coefficients" -x -q --timeout 180 --timeout-method thread
+root=$PWD; export TMPDIR=/tmp; cd /tmp
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/s37_stats -o p -- python3 $root/tools/const_faces_kernels.py 256 2
