@@ -170,10 +170,11 @@ def test_constant_coefficients_on_general_faces_fused_path(orc, bc, L):
 
 
 @pytest.mark.parametrize("L", [1, 2])
-@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9), (16, 62, 16), (128, 8, 8)])
+@pytest.mark.parametrize("n", [(40, 20, 28), (130, 12, 9), (16, 62, 16), (128, 8, 8), (4, 4, 4), (5, 4, 6)])
 def test_constant_coefficients_on_general_faces_ragged_shapes(orc, n, L):
     """mx a multiple of the tile width (the upper x face then lies in the halo column), several
-    tiles per row, tile edges inside the ghost layer, chunks of a few planes."""
+    tiles per row, tile edges inside the ghost layer, chunks of a few planes; the smallest boxes
+    the library takes (every cell but a few lies on or behind a face)."""
     q = P.smooth_var(n, bc=(1, 1, 1, 1, 1, 1))
     p = P.Problem("const", q.mx, q.delx, q.bc, False, False, (1., 2., 3.), q.phi, q.rhs, q.lam)
     p.rhs = np.random.default_rng(15).uniform(-1, 1, p.rhs.shape)
