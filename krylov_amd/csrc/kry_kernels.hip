@@ -499,6 +499,50 @@ __device__ __forceinline__ double bc_psi(const PsiSrc &s, const KryGeo &g, doubl
 	return psi_comb(az.mode, fa, ey(az.b));
 }
 
+// bc_psi with the memory accesses of all the untreated values it needs issued before any of them is
+// used (the nested form above waits for one cell's operands before it asks for the next: up to eight
+// memory latencies in a row).  Same values, same products and differences in the same order.
+__device__ __forceinline__ double bc_psi_batched(const PsiSrc &s, const KryGeo &g, int i, int j, int k)
+{
+	PsiAxis ax = {P_ID, i, i}, ay = {P_ID, j, j}, az = {P_ID, k, k};
+	const bool touched = !(i > 0 && i < g.mx && j > 0 && j < g.my && k > 0 && k < g.mz) &&
+	                     !(i < -1 || i > g.mx + 1 || j < -1 || j > g.my + 1 || k < -1 || k > g.mz + 1);
+	if (touched) {
+		ax = psi_axis(i, g.mx, g.nb[0], g.nb[1], g.bc[0], g.bc[1], false);
+		const bool in_x = (i >= 0 && i <= g.mx);
+		if (in_x) ay = psi_axis(j, g.my, g.nb[2], g.nb[3], g.bc[2], g.bc[3], false);
+		if (in_x && j >= 0 && j <= g.my) az = psi_axis(k, g.mz, g.has_lo, g.has_hi, g.bc[4], g.bc[5], true);
+	}
+	if (ax.mode == P_ZERO || ay.mode == P_ZERO || az.mode == P_ZERO) return 0.;
+	// corner m of the 2 x 2 x 2 set of untreated cells: bit 0 picks ax.b, bit 1 ay.b, bit 2 az.b
+	double x[8], y[8], z1[8], z2[8];
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		x[m] = y[m] = z1[m] = z2[m] = 0.;
+		const bool need = (!(m & 1) || ax.mode != P_ID) && (!(m & 2) || ay.mode != P_ID) && (!(m & 4) || az.mode != P_ID);
+		if (need) {
+			const long p = kry_idx(g, (m & 1) ? ax.b : ax.a, (m & 2) ? ay.b : ay.a, (m & 4) ? az.b : az.a);
+			x[m] = s.X[p];
+			y[m] = s.Y[p];
+			if (s.nz >= 1) z1[m] = s.Z1[p];
+			if (s.nz >= 2) z2[m] = s.Z2[p];
+		}
+	}
+	double f[8];
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		double yy = y[m];
+		if (s.nz >= 1) yy = axpy1(yy, z1[m], s.dz1);
+		if (s.nz >= 2) yy = axpy1(yy, z2[m], s.dz2);
+		f[m] = axpy1(x[m], yy, s.c);
+	}
+#pragma unroll
+	for (int m = 0; m < 8; m += 2) f[m] = (ax.mode == P_ID) ? f[m] : psi_comb(ax.mode, f[m], f[m + 1]);
+#pragma unroll
+	for (int m = 0; m < 8; m += 4) f[m] = (ay.mode == P_ID) ? f[m] : psi_comb(ay.mode, f[m], f[m + 2]);
+	return (az.mode == P_ID) ? f[0] : psi_comb(az.mode, f[0], f[4]);
+}
+
 template <int KIND> struct KindTraits;
 template <> struct KindTraits<KF_A0>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
 template <> struct KindTraits<KF_A1>   { static constexpr int ND = 1; static constexpr bool UPD = true;  };
@@ -1807,7 +1851,7 @@ __global__ __launch_bounds__(256) void g_psi_shell(const KryFused a, int is_a, i
 			i = q < 2 ? q - 1 : g.mx + q - 2;
 		}
 	}
-	a.Xout[kry_idx(g, i, j, k)] = bc_psi(src, g, psi_raw(src, g, i, j, k), i, j, k);
+	a.Xout[kry_idx(g, i, j, k)] = bc_psi_batched(src, g, i, j, k);
 }
 
 // g_bc_xy for the output of a general-boundary stencil kernel whose tile rows start at j = 0 (a.y_off == 0):
