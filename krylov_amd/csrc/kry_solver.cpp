@@ -1565,6 +1565,25 @@ void choose_chunk_depth(kry_solver *h)
 				if (rounds < 1.5) break;                     // the grid does not fill the device anyway
 				if (last == 0. || last >= 0.7 || rounds >= 12.) { nch = n; break; }
 			}
+			// Grids that are no multiple of the tile often do better with fewer, deeper chunks that fill the block
+			// slots nearly a whole number of times.  Estimated time of a launch = rounds over the slots x plane steps
+			// of a block (depth + the planes of its prologue); a partly filled round counts by its share of the memory
+			// bandwidth (a compute unit left with one block draws three quarters of its share), and never less than
+			// half a round (its blocks still march through their chunk).  The chunk count with the least estimate
+			// among those with chunks of 8 planes or more that fill the device replaces the choice above where the
+			// estimate is 5 % better (measured: n = 132: +9 %, 160: +4-7 %, 200: 0-7 %, 260: +5 %; 276: unchanged).
+			auto estimate = [&](int n) {
+				const double r = tiles * (double)n / slots;
+				const double full = std::floor(r), f = r - full;
+				const double part = f > 0. ? std::max(0.5, f / (0.75 + 0.5 * std::max(0., f - 0.5))) : 0.;
+				return (full + part) * ((nz + n - 1) / n + 3);
+			};
+			int best = 0;
+			for (int n = n_min; (nz + n - 1) / n >= 8 && (long)tiles * n <= 12 * slots; ++n) {
+				if (tiles * (double)n / slots < 0.9) continue;
+				if (!best || estimate(n) < estimate(best)) best = n;
+			}
+			if (best && estimate(best) < 0.95 * estimate(nch)) nch = best;
 		}
 	}
 	h->zc = (nz + nch - 1) / nch;      // even chunks
